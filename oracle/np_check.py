@@ -1,0 +1,247 @@
+"""Independent numpy/scipy re-implementation of the sigma-point filters (G6 of SURVEY.md 8c).
+
+TEST INFRASTRUCTURE ONLY.  Written separately from oracle/slk_oracle.c, on top of
+scipy.spatial.transform.Rotation / numpy.linalg, so that an error in the C oracle's
+SO(3), Cholesky, inverse or bookkeeping does not silently pass: tests require the two
+to agree to <= 1e-12 relative on every golden scenario.  It follows the same reference
+sources (src/filters/Msckf.hpp, Usckf.hpp, State.hpp) but shares no code with the oracle.
+"""
+import numpy as np
+from scipy.spatial.transform import Rotation as Rot
+
+CHI2_95 = {1: 3.84, 2: 5.99, 3: 7.81, 4: 9.49, 5: 11.07, 6: 12.59, 7: 14.07, 8: 15.51, 9: 16.92}
+
+
+class Manifold:
+    """A product of vector blocks and SO(3) blocks; storage quaternion order (x,y,z,w)."""
+
+    def __init__(self, blocks):
+        # blocks: list of (is_so3, tangent_offset, storage_offset, length)
+        self.blocks = blocks
+        self.N = max(t + l for _, t, _, l in blocks)
+        self.Nq = max(s + (4 if so3 else l) for so3, _, s, l in blocks)
+
+    @staticmethod
+    def _state_blocks(t0, s0):
+        return [(False, t0, s0, 3), (True, t0 + 3, s0 + 3, 3), (False, t0 + 6, s0 + 7, 3), (False, t0 + 9, s0 + 10, 3)]
+
+    @classmethod
+    def single(cls):
+        return cls(cls._state_blocks(0, 0))
+
+    @classmethod
+    def multi(cls, k):
+        b = cls._state_blocks(0, 0)
+        for c in range(k):
+            b += [(False, 12 + 6 * c, 13 + 7 * c, 3), (True, 15 + 6 * c, 16 + 7 * c, 3)]
+        return cls(b)
+
+    @classmethod
+    def augmented(cls, nfk, nfkl):
+        b = []
+        for s in range(3):
+            b += cls._state_blocks(12 * s, 13 * s)
+        if nfk:
+            b.append((False, 36, 39, nfk))
+        if nfkl:
+            b.append((False, 36 + nfk, 39 + nfk, nfkl))
+        m = cls(b)
+        m.N, m.Nq = 36 + nfk + nfkl, 39 + nfk + nfkl
+        return m
+
+    def plus(self, x, v):
+        out = np.array(x, dtype=float)
+        for so3, t, s, l in self.blocks:
+            if so3:
+                out[s:s + 4] = (Rot.from_quat(x[s:s + 4]) * Rot.from_rotvec(v[t:t + 3])).as_quat()
+                # scipy canonicalises nothing here; keep the sign continuous with the product
+            else:
+                out[s:s + l] = x[s:s + l] + v[t:t + l]
+        return out
+
+    def minus(self, a, b):
+        out = np.zeros(self.N)
+        for so3, t, s, l in self.blocks:
+            if so3:
+                out[t:t + 3] = (Rot.from_quat(b[s:s + 4]).inv() * Rot.from_quat(a[s:s + 4])).as_rotvec()
+            else:
+                out[t:t + l] = a[s:s + l] - b[s:s + l]
+        return out
+
+    def mean(self, X):
+        ref = X[0].copy()
+        it = 0
+        while True:
+            md = np.mean([self.minus(x, ref) for x in X], axis=0)
+            ref = self.plus(ref, md)
+            it += 1
+            if not (np.linalg.norm(md) > 1e-6 and it < 10000):
+                break
+        return ref, it
+
+    def sigma(self, mu, delta, P):
+        L = np.linalg.cholesky(P)
+        X = [self.plus(mu, delta)]
+        for j in range(self.N):
+            X.append(self.plus(mu, delta + L[:, j]))
+            X.append(self.plus(mu, delta - L[:, j]))
+        return X
+
+    def cov(self, mean, X):
+        D = np.array([self.minus(x, mean) for x in X])
+        return 0.5 * D.T @ D
+
+
+# ---------------------------------------------------------------- models
+def pm_const_velocity(x, velocity, angular_velocity, dt):
+    y = np.zeros(13)
+    y[3:7] = (Rot.from_quat(x[3:7]) * Rot.from_rotvec(np.asarray(angular_velocity) * dt)).as_quat()
+    y[10:13] = angular_velocity
+    y[7:10] = velocity
+    y[0:3] = x[0:3] + x[7:10] * dt
+    return y
+
+
+def pm_delta_pose(x, dpos, dquat, velocity, angular_velocity):
+    y = np.zeros(13)
+    r = Rot.from_quat(x[3:7]) * Rot.from_quat(dquat)
+    y[3:7] = r.as_quat()
+    y[10:13] = angular_velocity
+    y[0:3] = x[0:3] + r.apply(dpos)
+    y[7:10] = velocity
+    return y
+
+
+def mm_vo_relative(X, nfk):
+    single = Manifold.single()
+    d = single.minus(X[0:13], X[26:39])
+    R = Rot.from_rotvec(d[3:6])
+    z = X[39:39 + nfk].copy()
+    for i in range(0, nfk - 2, 3):
+        z[i:i + 3] = R.apply(X[39 + i:39 + i + 3]) + d[0:3]
+    return z
+
+
+def _pose(X, c, kind):
+    if kind == "multi":
+        s = 0 if c == 0 else 13 + 7 * (c - 1)
+    else:
+        s = 13 * c
+    return X[s:s + 3], X[s + 3:s + 7]
+
+
+def mm_feature_proj(X, feat, kind="multi"):
+    feat = np.asarray(feat, dtype=float).reshape(-1, 4)
+    z = []
+    for lx, ly, lz, c in feat:
+        p, q = _pose(X, int(c), kind)
+        loc = Rot.from_quat(q).inv().apply(np.array([lx, ly, lz]) - p)
+        z += [loc[0] / loc[2], loc[1] / loc[2]]
+    return np.array(z)
+
+
+def mm_pose_position(X, c, kind="multi"):
+    return _pose(X, int(c), kind)[0].copy()
+
+
+# ---------------------------------------------------------------- filters
+def predict_single(state, Pi, f, Q):
+    man = Manifold.single()
+    X0 = man.sigma(state, np.zeros(12), Pi)
+    X1 = [f(x) for x in X0]
+    mean_new, it = man.mean(X1)
+    Dx = np.array([man.minus(x, state) for x in X0])
+    Dy = np.array([man.minus(x, mean_new) for x in X1])
+    Pxy = 0.5 * Dx.T @ Dy
+    Fk = Pxy.T @ np.linalg.inv(Pi)
+    return mean_new, 0.5 * Dy.T @ Dy + Q, Fk, it
+
+
+class Msckf:
+    def __init__(self, k, mean, P):
+        self.man = Manifold.multi(k)
+        self.mean = np.array(mean, dtype=float)
+        self.P = np.array(P, dtype=float)
+
+    def predict(self, f, Q):
+        s, Pi, self.Fk, it = predict_single(self.mean[:13], self.P[:12, :12], f, Q)
+        self.mean[:13] = s
+        self.P[:12, :12] = Pi
+        return it
+
+    def update(self, z, h, R, gate=True):
+        man, N = self.man, self.man.N
+        X = man.sigma(self.mean, np.zeros(N), self.P)
+        Z = np.array([h(x) for x in X])
+        zbar = Z.sum(axis=0) / len(Z)
+        innov = np.asarray(z, dtype=float) - zbar
+        dZ = Z - zbar
+        S = 0.5 * dZ.T @ dZ + R
+        D = np.array([man.minus(x, self.mean) for x in X])
+        C = 0.5 * D.T @ dZ
+        # removeOutliers with the reference's shifted second erase (Msckf.hpp:741-744)
+        idx = list(range(len(innov)))
+        outliers, i = 0, 0
+
+        def erase(lst, pos):
+            if pos < len(lst) - 1:
+                del lst[pos]
+            else:
+                del lst[-1]
+
+        while i < len(idx) // 2:
+            a, b = idx[2 * i], idx[2 * i + 1]
+            r = innov[[a, b]]
+            d2 = r @ np.linalg.inv(S[np.ix_([a, b], [a, b])]) @ r
+            if gate and not d2 < CHI2_95[2]:
+                erase(idx, 2 * i)
+                erase(idx, 2 * i + 1)
+                outliers += 1
+            else:
+                i += 1
+        if idx:
+            Sr = S[np.ix_(idx, idx)]
+            K = C[:, idx] @ np.linalg.inv(Sr)
+            self.P = self.P - K @ Sr @ K.T
+            delta = K @ innov[idx]
+            X = man.sigma(self.mean, delta, self.P)
+            self.mean, it = man.mean(X)
+            self.P = man.cov(self.mean, X)
+        return outliers
+
+
+class Usckf:
+    def __init__(self, nfk, nfkl, mean, P):
+        self.nfk, self.nfkl = nfk, nfkl
+        self.mean = np.array(mean, dtype=float)
+        self.P = np.array(P, dtype=float)
+
+    @property
+    def man(self):
+        return Manifold.augmented(self.nfk, self.nfkl)
+
+    def predict(self, f, Q):
+        s, Pi, Fk, it = predict_single(self.mean[26:39], self.P[24:36, 24:36], f, Q)
+        P = self.P
+        self.mean[26:39] = s
+        P[24:36, 24:36] = Pi
+        P[0:12, 24:36] = P[0:12, 24:36] @ Fk.T
+        P[12:24, 24:36] = P[12:24, 24:36] @ Fk.T
+        P[24:36, 0:12] = Fk @ P[24:36, 0:12]
+        P[24:36, 12:24] = Fk @ P[24:36, 12:24]
+        if self.nfk + self.nfkl:
+            P[24:36, 36:] = Fk @ P[24:36, 36:]
+            P[36:, 24:36] = P[24:36, 36:].T
+        return it
+
+    def update(self, z, h, R):
+        man, N = self.man, self.man.N
+        X = man.sigma(self.mean, np.zeros(N), self.P)
+        Z = np.array([h(x) for x in X])
+        zbar = Z.sum(axis=0) / len(Z)
+        dZ = Z - zbar
+        S = 0.5 * dZ.T @ dZ + R
+        D = np.array([man.minus(x, self.mean) for x in X])
+        K = (0.5 * D.T @ dZ) @ np.linalg.inv(S)
+        self.P = self.P - K @ S @ K.T
+        self.mean = man.plus(self.mean, K @ (np.asarray(z, dtype=float) - zbar))

@@ -1,0 +1,97 @@
+"""The CPU oracle against the committed golden fixtures (tests/golden/*.npz, written by
+tests/golden/make_golden.py) and against the independent numpy/scipy implementation (G6).
+Golden vectors are oracle-generated: the reference holds none ("parity unpinned")."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import np_check as npc
+from oracle import oracle as o
+import scenarios as sc
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-12
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(1e-300, np.abs(b).max()))
+
+
+def test_usckf_unit_test_golden():
+    g = np.load(os.path.join(G, "usckf_unit_test.npz"))
+    u = sc.usckf_unit_test()
+    f = o.Usckf(state13=u["state_single"], P0_12=u["P0_single"])
+    assert rel(f.P, g["ctor_P"]) <= TOL
+    for i, (mode, z, R) in enumerate(u["set_measurements"]):
+        f.set_measurement(mode, z, R)
+        assert rel(f.P, g[f"setm{i}_P"]) <= TOL
+        np.testing.assert_allclose(f.mean, g[f"setm{i}_mean"], rtol=TOL, atol=TOL)
+    pm = o.pm_const_velocity(u["velocity"], u["angular_velocity"], u["dt"])
+    for i in range(u["n_predict"]):
+        assert f.predict(pm, u["Q"]) == 0
+        assert rel(f.P, g[f"pred{i}_P"]) <= TOL
+        assert np.abs(o.boxminus(f.lay, f.mean, g[f"pred{i}_mean"])).max() <= TOL
+    assert int(g["literal_update_status"][0]) & o.LLT_FAIL
+
+
+@pytest.mark.parametrize("k", [0, 1, 4, 8, 31])
+def test_msckf_unit_test_golden(k):
+    g = np.load(os.path.join(G, "msckf_unit_test.npz"))
+    t = sc.msckf_unit_test(k)
+    f = o.Msckf(k, t["mean"], t["P"])
+    pm = o.pm_delta_pose(t["dpos"], t["dquat"], t["velocity"], t["angular_velocity"])
+    for i in range(t["n_predict"]):
+        assert f.predict(pm, t["Q"]) == 0
+        assert rel(f.P, g[f"k{k}_pred{i}_P"]) <= TOL
+        assert np.abs(o.boxminus(f.lay, f.mean, g[f"k{k}_pred{i}_mean"])).max() <= TOL
+    R = 0.01 * np.eye(g[f"k{k}_z"].size)
+    st, no = f.update(g[f"k{k}_z"], o.mm_feature_proj(g[f"k{k}_feat"]), R)
+    assert st == 0 and no == int(g[f"k{k}_outliers"][0])
+    assert rel(f.P, g[f"k{k}_upd_P"]) <= TOL
+    assert np.abs(o.boxminus(f.lay, f.mean, g[f"k{k}_upd_mean"])).max() <= TOL
+
+
+def test_msckf_batch_golden_and_np_crosscheck():
+    g = np.load(os.path.join(G, "msckf_batch.npz"))
+    s = sc.synthetic_msckf(8, 8)
+    # through the batch driver (the cpu_baseline code path)
+    mean, P = s["mean"].copy(), s["P"].copy()
+    st, out = o.msckf_step_batch(8, 8, 3, mean, P, s["u"], s["feat"], g["z"], s["Q"], s["R"])
+    assert st == 0
+    np.testing.assert_array_equal(out, g["outliers"])
+    lay = o.layout(o.MULTI, 8)
+    for b in range(8):
+        Pb = P[b].reshape(60, 60).T                 # batch driver keeps column-major per filter
+        assert rel(Pb, g["P"][b]) <= TOL
+        assert np.abs(o.boxminus(lay, mean[b], g["mean"][b])).max() <= TOL
+    # independent numpy/scipy implementation on one filter with outliers (b = 2)
+    b = 2
+    gnp = npc.Msckf(8, s["mean"][b], s["P"][b])
+    u = s["u"][b]
+    tot = 0
+    for _ in range(3):
+        gnp.predict(lambda x: npc.pm_delta_pose(x, u[0:3], u[3:7], u[7:10], u[10:13]), s["Q"])
+        tot += gnp.update(g["z"][b], lambda X: npc.mm_feature_proj(X, s["feat"][b]), s["R"])
+    assert tot == int(g["outliers"][b]) and tot > 0
+    assert rel(gnp.P, g["P"][b]) <= TOL
+    assert np.abs(o.boxminus(lay, gnp.mean, g["mean"][b])).max() <= TOL
+
+
+def test_usckf_spd_golden_and_np_crosscheck():
+    g = np.load(os.path.join(G, "usckf_spd.npz"))
+    s = sc.synthetic_usckf(4)
+    for b in range(4):
+        f = o.Usckf(nfk=3, nfkl=9, mean=s["mean"][b], P=s["P"][b])
+        gnp = npc.Usckf(3, 9, s["mean"][b], s["P"][b])
+        u = s["u"][b]
+        pm = o.pm_const_velocity(u[0:3], u[3:6], u[6])
+        for _ in range(2):
+            assert f.predict(pm, s["Q"]) == 0
+            st, acc = f.update(s["z"][b], o.mm_vo_relative(), s["R"])
+            assert st == 0 and acc == 1
+            gnp.predict(lambda x: npc.pm_const_velocity(x, u[0:3], u[3:6], u[6]), s["Q"])
+            gnp.update(s["z"][b], lambda X: npc.mm_vo_relative(X, 3), s["R"])
+        assert rel(f.P, g["P"][b]) <= TOL and rel(gnp.P, g["P"][b]) <= TOL
+        assert np.abs(o.boxminus(f.lay, f.mean, g["mean"][b])).max() <= TOL
+        assert np.abs(o.boxminus(f.lay, gnp.mean, g["mean"][b])).max() <= TOL
