@@ -1,0 +1,167 @@
+/*
+ * slk.h -- C ABI of the MI355X-native sigma-point Kalman hot path
+ *          ("slk" = sigma-point localization kernels).
+ *
+ * Drop-in boundary for the predict()/update() path of
+ *   localization::Msckf<_MultiState,_SingleState>      reference src/filters/Msckf.hpp
+ *   localization::Usckf<_AugmentedState,_SingleState>  reference src/filters/Usckf.hpp
+ * The reference is a header-only C++ template library with no FFI of its own; this is the
+ * interface its filter classes bind to when they are backed by the GPU (the header facade
+ * under include/localization/filters/ calls exactly these entry points; INTEGRATION.md shows
+ * the binding).  One handle = a BATCH of B independent filters of identical layout on one
+ * device; B = 1 reproduces the reference object.
+ *
+ * Conventions
+ *   - fp64 everywhere (the reference scalar is double: src/filters/State.hpp:37-38).
+ *   - matrices are column-major (Eigen default), one filter after the other:
+ *       mean [B][Nq], P [B][N*N], Q [12*12], R [m*m].
+ *   - quaternions are stored (x, y, z, w) like Eigen::Quaternion::coeffs().
+ *   - State   storage (13): pos[3] quat[4] velo[3] angvelo[3], tangent DOF 12 (State.hpp:137-149)
+ *     Sensor  storage  (7): pos[3] quat[4],                    tangent DOF  6 (State.hpp:242-252)
+ *     Msckf mean  = State + k * Sensor            N = 12 + 6k      (State.hpp:336-376)
+ *     Usckf mean  = statek, statek_l, statek_i, featuresk[nfk], featuresk_l[nfkl]
+ *                                                 N = 36 + nfk + nfkl (State.hpp:529-593)
+ *   - every pointer argument is host or device memory as said by the `where` argument of the
+ *     call (SLK_HOST: the library stages it through its own device buffers; SLK_DEVICE: used
+ *     in place, must be resident on the handle's device).
+ *   - return value: 0 = ok, < 0 = API / runtime error (nothing was changed).  Numerical
+ *     conditions are per-filter STATUS bits (slk_get_status); the reference has no error
+ *     reporting at all (asserts / silently ignored LLT failure: Usckf.hpp:537-538, 620-624).
+ *   - a handle is not thread-safe; distinct handles may be used concurrently.  All work of a
+ *     handle is ordered on one HIP stream.
+ */
+#ifndef SLK_H
+#define SLK_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLK_ABI_VERSION 1
+
+typedef struct slk_filter slk_filter;
+
+enum { SLK_MSCKF = 1, SLK_USCKF = 2 };
+enum { SLK_HOST = 0, SLK_DEVICE = 1 };
+
+/* error codes */
+enum {
+    SLK_OK = 0,
+    SLK_E_INVALID = -1,      /* bad argument / size mismatch (reference: assert, Usckf.hpp:325-327) */
+    SLK_E_NO_DEVICE = -2,    /* no usable HIP device: the product has NO CPU fallback */
+    SLK_E_HIP = -3,          /* HIP runtime error, see slk_last_error() */
+    SLK_E_UNSUPPORTED = -4,  /* shape outside what the kernels are built for */
+    SLK_E_NOMEM = -5
+};
+
+/* per-filter status bits (OR-accumulated until slk_clear_status) */
+enum {
+    SLK_ST_LLT_FAIL = 1,            /* non-positive Cholesky pivot; that call left the filter unchanged */
+    SLK_ST_MEAN_NOT_CONVERGED = 2,  /* manifold mean hit max_it = 10000 (Msckf.hpp:475,489-493) */
+    SLK_ST_SINGULAR = 4,            /* innovation covariance not invertible */
+    SLK_ST_ALL_REJECTED = 8         /* every measurement block failed the gate: update skipped (Msckf.hpp:250) */
+};
+
+/* cloning modes of Usckf (Usckf.hpp:37-42) */
+enum { SLK_STATEK = 1, SLK_STATEK_L = 2, SLK_STATEK_I = 3 };
+
+/* Registered process models f: SingleState -> SingleState (Tier A, run on the GPU).
+ * SLK_MODEL_EXTERNAL = opaque host functor (Tier B): the caller maps the sigma points itself. */
+enum {
+    SLK_MODEL_EXTERNAL = 0,
+    SLK_PM_CONST_VELOCITY = 1,  /* test/UsckfUnitTest.cpp:34-49; u = velocity[3] angular_velocity[3] dt  (7) */
+    SLK_PM_DELTA_POSE = 2       /* test/MsckfUnitTest.cpp:33-47; u = dpos[3] dquat[4] velocity[3] angular_velocity[3] (13) */
+};
+
+/* Registered measurement models h: FullState -> R^m */
+enum {
+    SLK_MM_VO_RELATIVE = 1,     /* test/UsckfUnitTest.cpp:62-86 (Usckf only); no parameters, m = nfk */
+    SLK_MM_FEATURE_PROJ = 2,    /* m/2 landmarks seen as normalised image points from a pose;
+                                   params = (m/2) x { landmark xyz, pose index }; pose 0 = current
+                                   state, c >= 1 = clone c-1 (Msckf) / 0,1,2 = statek,statek_l,statek_i (Usckf) */
+    SLK_MM_POSE_POSITION = 3    /* z = position of pose params[0]; m = 3 */
+};
+
+typedef struct {
+    int kind;            /* SLK_MSCKF / SLK_USCKF */
+    int batch;           /* B >= 1 independent filters */
+    int device;          /* HIP device ordinal */
+    int n_clones;        /* Msckf: k sensor-pose clones (MultiState::sensorsk.size()) */
+    int n_featuresk;     /* Usckf: |featuresk| */
+    int n_featuresk_l;   /* Usckf: |featuresk_l| */
+    void *stream;        /* hipStream_t to run on, or NULL for a library-owned stream */
+} slk_config;
+
+/* ---- lifetime: replaces the filter constructors (Msckf.hpp:80-85, Usckf.hpp:83-103) ---- */
+int  slk_create(const slk_config *cfg, slk_filter **out);
+void slk_destroy(slk_filter *f);
+const char *slk_last_error(void);
+int  slk_device_count(void);
+
+int slk_batch(const slk_filter *f);
+int slk_dof(const slk_filter *f);       /* N  = getDOF()            (State.hpp:373-376, 590-593) */
+int slk_storage(const slk_filter *f);   /* Nq = stored mean length */
+
+/* ---- state access: muState()/getPk()/setPk()/muSingleState() (Msckf.hpp:351-395,
+ *      Usckf.hpp:435-526).  mean [B][Nq], P [B][N*N]; either may be NULL. ---- */
+int slk_set_state(slk_filter *f, const double *mean, const double *P, int where);
+int slk_get_state(slk_filter *f, double *mean, double *P, int where);
+double *slk_mean_device_ptr(slk_filter *f);   /* resident buffers, for zero-copy callers */
+double *slk_cov_device_ptr(slk_filter *f);
+
+/* ---- predict(f, Q): Msckf.hpp:89-189, Usckf.hpp:107-244.
+ *      u [B][u_stride] model inputs (u_stride 0 = one shared row);
+ *      Q 12x12 (q_stride 0 = shared, else per-filter stride in doubles). ---- */
+int slk_predict(slk_filter *f, int model, const double *u, int u_stride,
+                const double *Q, int q_stride, int where);
+
+/* ---- update(z, h, R[, mt]): UKF update, Msckf.hpp:196-277 (chi-square gate per 2-row block
+ *      + applyDelta re-draw) and Usckf.hpp:246-308 (whole-vector gate, direct boxplus).
+ *      params [B][p_stride] model parameters (0 = shared), z [B][m], R m x m (r_stride 0 = shared).
+ *      gate: Msckf 0 = accept all blocks, 1 = accept_mahalanobis_distance (Msckf.hpp:199,844-905);
+ *            Usckf 0 = accept_any (Usckf.hpp:249), d = chi-square dof of the whole-vector gate. ---- */
+int slk_update(slk_filter *f, int model, const double *params, int p_stride,
+               const double *z, int m, const double *R, int r_stride, int gate, int where);
+
+/* ---- fused predict + update, one kernel launch, state stays on chip between the two
+ *      (the benchmark's "filter step") ---- */
+int slk_step(slk_filter *f, int pmodel, const double *u, int u_stride, const double *Q, int q_stride,
+             int mmodel, const double *params, int p_stride, const double *z, int m,
+             const double *R, int r_stride, int gate, int where);
+
+/* ---- Tier B (opaque host functors, the reference's boost::bind form:
+ *      UsckfUnitTest.cpp:246,284; MsckfUnitTest.cpp:200-205).  The library draws the sigma
+ *      points (generateSigmaPoints, Msckf.hpp:400-468 / Usckf.hpp:532-598), the caller applies
+ *      f / h, the library finishes the step with the same kernels as Tier A. ---- */
+int slk_predict_sigma_points(slk_filter *f, double *X /* [B][25][13] */, int where);
+int slk_predict_from_sigma(slk_filter *f, const double *Y /* [B][25][13] = f(X) */,
+                           const double *Q, int q_stride, int where);
+int slk_update_sigma_points(slk_filter *f, double *X /* [B][2N+1][Nq] */, int where);
+int slk_update_from_sigma(slk_filter *f, const double *Z /* [B][2N+1][m] = h(X) */,
+                          const double *z, int m, const double *R, int r_stride, int gate, int where);
+
+/* ---- Usckf bookkeeping: cloning() Usckf.hpp:391-433, setMeasurement() Usckf.hpp:322-389
+ *      (changes N; z [B][n], R n x n shared) ---- */
+int slk_usckf_cloning(slk_filter *f, int mode);
+int slk_usckf_set_measurement(slk_filter *f, int mode, const double *z, int n, const double *R, int where);
+/* Msckf sliding window: caller-side push/pop on muState().sensorsk + setPk (Msckf.hpp:381-395) */
+int slk_msckf_resize(slk_filter *f, int n_clones);
+
+/* ---- results of the last update / accumulated status ---- */
+int slk_get_outliers(slk_filter *f, unsigned *outliers /* [B], return value of Msckf::update :276 */, int where);
+int slk_get_status(slk_filter *f, int *status /* [B] */, int where);
+int slk_clear_status(slk_filter *f);
+int slk_sync(slk_filter *f);
+
+/* ---- measurement aids (HIP events on the handle's stream) ---- */
+int slk_timer_start(slk_filter *f);
+int slk_timer_stop(slk_filter *f, float *milliseconds);
+
+/* self test of the fp64 MFMA fragment layout used by the covariance rebuild: multiplies an
+ * asymmetric 16x16 pair on the device and checks it on the host.  0 = layout as documented. */
+int slk_selftest_mfma(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLK_H */

@@ -12,7 +12,20 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _BUILD = os.path.join(_HERE, "_build")
-_SO = os.path.join(_BUILD, "libslk_oracle.so")
+
+
+def _host_tag():
+    """-march=native code must not travel between machines: key the build on the host CPU."""
+    import hashlib
+    try:
+        with open("/proc/cpuinfo") as fh:
+            lines = [l for l in fh if l.startswith(("model name", "flags"))][:2]
+    except OSError:
+        lines = []
+    return hashlib.sha1("".join(lines).encode()).hexdigest()[:10]
+
+
+_SO = os.path.join(_BUILD, "libslk_oracle_%s.so" % _host_tag())
 
 SINGLE, MULTI, AUGMENTED = 0, 1, 2
 STATEK, STATEK_L, STATEK_I = 1, 2, 3
@@ -20,7 +33,7 @@ OK, LLT_FAIL, MEAN_NOT_CONVERGED, SINGULAR = 0, 1, 2, 4
 
 
 def build(force=False, opt="-O3"):
-    """Compile the oracle with gcc (no -ffast-math: fp64 semantics must stay IEEE)."""
+    """Compile the oracle with gcc (ISO C mode: no FMA contraction, no -ffast-math; fp64 stays IEEE)."""
     src = os.path.join(_HERE, "slk_oracle.c")
     hdr = os.path.join(_HERE, "slk_oracle.h")
     if (not force and os.path.exists(_SO)

@@ -1,0 +1,31 @@
+"""Build the HIP shared library in-tree: slam-localization_amd/libslk_hip.so (gfx950 only)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "slk_api.hip")
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("slk_api.hip", "slk_kernels.hpp", "slk_usckf.hpp", "slk_math.hpp")]
+DEPS.append(os.path.join(os.path.dirname(HERE), "include", "slk.h"))
+OUT = os.path.join(HERE, "libslk_hip.so")
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in DEPS):
+        return OUT
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT, SRC]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

@@ -1,0 +1,540 @@
+// slk_api.hip -- host side of the C ABI declared in include/slk.h.
+// Owns the batch's device buffers, stages host arguments, picks the kernel instantiation and
+// launches on the handle's stream.  There is NO CPU fallback: without a HIP device every
+// entry point fails with SLK_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/slk.h"
+#include "slk_kernels.hpp"
+#include "slk_usckf.hpp"
+
+using namespace slk;
+
+static thread_local std::string g_err;
+
+#define HIPCHECK(expr)                                                                   \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+            return SLK_E_HIP;                                                            \
+        }                                                                                \
+    } while (0)
+
+struct Stage {
+    double *p = nullptr;
+    size_t cap = 0;
+};
+
+struct slk_filter {
+    slk_config cfg;
+    Lay lay;
+    int B;
+    hipStream_t stream;
+    bool own_stream;
+    double *d_mean, *d_P;
+    size_t cap_mean, cap_P;       // capacities in doubles (per batch), so resizes can stay in place
+    int *d_status;
+    unsigned *d_outliers;
+    Stage st_u, st_Q, st_mp, st_z, st_R, st_X, st_Z, st_tmpP, st_tmpM;
+    hipEvent_t ev0, ev1;
+};
+
+static Lay make_lay(int kind, int k, int nfk, int nfkl)
+{
+    Lay L;
+    L.kind = kind; L.k = k; L.nfk = nfk; L.nfkl = nfkl;
+    if (kind == SLK_MSCKF) { L.N = 12 + 6 * k; L.Nq = 13 + 7 * k; L.nso3 = 1 + k; }
+    else { L.N = 36 + nfk + nfkl; L.Nq = 39 + nfk + nfkl; L.nso3 = 3; }
+    return L;
+}
+
+static int stage_reserve(slk_filter *f, Stage &s, size_t n)
+{
+    if (s.cap >= n) return SLK_OK;
+    if (s.p) HIPCHECK(hipFree(s.p));
+    s.p = nullptr; s.cap = 0;
+    HIPCHECK(hipMalloc(&s.p, n * sizeof(double)));
+    s.cap = n;
+    (void)f;
+    return SLK_OK;
+}
+
+// returns a device pointer for `src` (n doubles): in place for SLK_DEVICE, staged copy for SLK_HOST
+static int stage_in(slk_filter *f, Stage &s, const double *src, size_t n, int where, const double **out)
+{
+    if (!src || n == 0) { *out = nullptr; return SLK_OK; }
+    if (where == SLK_DEVICE) { *out = src; return SLK_OK; }
+    int rc = stage_reserve(f, s, n);
+    if (rc) return rc;
+    HIPCHECK(hipMemcpyAsync(s.p, src, n * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    *out = s.p;
+    return SLK_OK;
+}
+
+extern "C" {
+
+const char *slk_last_error(void) { return g_err.c_str(); }
+
+int slk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int slk_create(const slk_config *cfg, slk_filter **out)
+{
+    if (!cfg || !out) return SLK_E_INVALID;
+    if (cfg->kind != SLK_MSCKF && cfg->kind != SLK_USCKF) return SLK_E_INVALID;
+    if (cfg->batch < 1 || cfg->n_clones < 0 || cfg->n_featuresk < 0 || cfg->n_featuresk_l < 0) return SLK_E_INVALID;
+    int ndev = slk_device_count();
+    if (ndev <= 0) { g_err = "no HIP device: the slk library has no CPU fallback"; return SLK_E_NO_DEVICE; }
+    if (cfg->device < 0 || cfg->device >= ndev) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(cfg->device));
+    slk_filter *f = new slk_filter();
+    f->cfg = *cfg;
+    f->lay = make_lay(cfg->kind, cfg->n_clones, cfg->n_featuresk, cfg->n_featuresk_l);
+    f->B = cfg->batch;
+    f->own_stream = (cfg->stream == nullptr);
+    if (f->own_stream) {
+        hipError_t e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { g_err = hipGetErrorString(e); delete f; return SLK_E_HIP; }
+    } else {
+        f->stream = (hipStream_t)cfg->stream;
+    }
+    f->d_mean = f->d_P = nullptr;
+    f->d_status = nullptr; f->d_outliers = nullptr;
+    size_t B = (size_t)f->B;
+    f->cap_mean = (size_t)f->lay.Nq; f->cap_P = (size_t)f->lay.N * f->lay.N;
+    bool ok = hipMalloc(&f->d_mean, B * f->cap_mean * sizeof(double)) == hipSuccess
+           && hipMalloc(&f->d_P, B * f->cap_P * sizeof(double)) == hipSuccess
+           && hipMalloc(&f->d_status, B * sizeof(int)) == hipSuccess
+           && hipMalloc(&f->d_outliers, B * sizeof(unsigned)) == hipSuccess
+           && hipEventCreate(&f->ev0) == hipSuccess && hipEventCreate(&f->ev1) == hipSuccess;
+    if (!ok) { g_err = "device allocation failed"; slk_destroy(f); return SLK_E_NOMEM; }
+    (void)hipMemsetAsync(f->d_status, 0, B * sizeof(int), f->stream);
+    (void)hipMemsetAsync(f->d_outliers, 0, B * sizeof(unsigned), f->stream);
+    (void)hipMemsetAsync(f->d_mean, 0, B * f->cap_mean * sizeof(double), f->stream);
+    (void)hipMemsetAsync(f->d_P, 0, B * f->cap_P * sizeof(double), f->stream);
+    *out = f;
+    return SLK_OK;
+}
+
+void slk_destroy(slk_filter *f)
+{
+    if (!f) return;
+    (void)hipSetDevice(f->cfg.device);
+    (void)hipStreamSynchronize(f->stream);
+    Stage *st[] = {&f->st_u, &f->st_Q, &f->st_mp, &f->st_z, &f->st_R, &f->st_X, &f->st_Z, &f->st_tmpP, &f->st_tmpM};
+    for (Stage *s : st) if (s->p) (void)hipFree(s->p);
+    if (f->d_mean) (void)hipFree(f->d_mean);
+    if (f->d_P) (void)hipFree(f->d_P);
+    if (f->d_status) (void)hipFree(f->d_status);
+    if (f->d_outliers) (void)hipFree(f->d_outliers);
+    (void)hipEventDestroy(f->ev0);
+    (void)hipEventDestroy(f->ev1);
+    if (f->own_stream) (void)hipStreamDestroy(f->stream);
+    delete f;
+}
+
+int slk_batch(const slk_filter *f) { return f ? f->B : SLK_E_INVALID; }
+int slk_dof(const slk_filter *f) { return f ? f->lay.N : SLK_E_INVALID; }
+int slk_storage(const slk_filter *f) { return f ? f->lay.Nq : SLK_E_INVALID; }
+double *slk_mean_device_ptr(slk_filter *f) { return f ? f->d_mean : nullptr; }
+double *slk_cov_device_ptr(slk_filter *f) { return f ? f->d_P : nullptr; }
+
+int slk_set_state(slk_filter *f, const double *mean, const double *P, int where)
+{
+    if (!f) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    hipMemcpyKind kind = where == SLK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    size_t B = (size_t)f->B;
+    if (mean) HIPCHECK(hipMemcpyAsync(f->d_mean, mean, B * f->lay.Nq * sizeof(double), kind, f->stream));
+    if (P) HIPCHECK(hipMemcpyAsync(f->d_P, P, B * f->lay.N * f->lay.N * sizeof(double), kind, f->stream));
+    if (where == SLK_HOST) HIPCHECK(hipStreamSynchronize(f->stream));   // caller may reuse its buffers
+    return SLK_OK;
+}
+
+int slk_get_state(slk_filter *f, double *mean, double *P, int where)
+{
+    if (!f) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    hipMemcpyKind kind = where == SLK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    size_t B = (size_t)f->B;
+    if (mean) HIPCHECK(hipMemcpyAsync(mean, f->d_mean, B * f->lay.Nq * sizeof(double), kind, f->stream));
+    if (P) HIPCHECK(hipMemcpyAsync(P, f->d_P, B * f->lay.N * f->lay.N * sizeof(double), kind, f->stream));
+    if (where == SLK_HOST) HIPCHECK(hipStreamSynchronize(f->stream));
+    return SLK_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------- launch helpers
+template <int NT, int NTHREADS>
+static int launch_msckf_inst(slk_filter *f, const KArgs &a)
+{
+    Carve cv = carve_step(a.lay.N, a.lay.Nq, a.m, a.lay.nso3, NT);
+    size_t lds = (size_t)cv.total * sizeof(double);
+    if (lds > 160 * 1024) { g_err = "state too large for the LDS-resident kernel"; return SLK_E_UNSUPPORTED; }
+    auto kern = msckf_step_kernel<NT, NTHREADS>;
+    static size_t configured = 0;
+    if (lds > configured) {
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(NTHREADS), lds, f->stream, a);
+    HIPCHECK(hipGetLastError());
+    return SLK_OK;
+}
+
+static int launch_msckf(slk_filter *f, const KArgs &a)
+{
+    int NT = (a.lay.N + 15) / 16;
+    switch (NT) {
+    case 1: return launch_msckf_inst<1, 64>(f, a);
+    case 2: return launch_msckf_inst<2, 64>(f, a);
+    case 3: return launch_msckf_inst<3, 256>(f, a);
+    case 4: return launch_msckf_inst<4, 256>(f, a);
+    case 5: return launch_msckf_inst<5, 256>(f, a);
+    case 6: return launch_msckf_inst<6, 256>(f, a);
+    default: g_err = "state dimension above 96 is not supported by this build"; return SLK_E_UNSUPPORTED;
+    }
+}
+
+static int launch_usckf(slk_filter *f, const KArgs &a)
+{
+    UCarve cv = carve_usckf(a.lay.N, a.lay.Nq, a.m);
+    size_t lds = (size_t)cv.total * sizeof(double);
+    if (lds > 160 * 1024) { g_err = "state too large for the LDS-resident kernel"; return SLK_E_UNSUPPORTED; }
+    auto kern = usckf_kernel<256>;
+    static size_t configured = 0;
+    if (lds > configured) {
+        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds, f->stream, a);
+    HIPCHECK(hipGetLastError());
+    return SLK_OK;
+}
+
+static void base_args(slk_filter *f, KArgs &a)
+{
+    memset(&a, 0, sizeof(a));
+    a.B = f->B;
+    a.lay = f->lay;
+    a.mean = f->d_mean; a.P = f->d_P; a.status = f->d_status; a.outliers = f->d_outliers;
+}
+
+static int pm_inputs(int model) { return model == SLK_PM_CONST_VELOCITY ? 7 : (model == SLK_PM_DELTA_POSE ? 13 : 0); }
+static int mm_params(int model, int m)
+{
+    return model == SLK_MM_FEATURE_PROJ ? (m / 2) * 4 : (model == SLK_MM_POSE_POSITION ? 1 : 0);
+}
+
+static int fill_predict(slk_filter *f, KArgs &a, int model, const double *u, int u_stride,
+                        const double *Q, int q_stride, int where)
+{
+    if (model != SLK_PM_CONST_VELOCITY && model != SLK_PM_DELTA_POSE) return SLK_E_INVALID;
+    if (!u || !Q) return SLK_E_INVALID;
+    int nu = pm_inputs(model);
+    if (u_stride != 0 && u_stride < nu) return SLK_E_INVALID;
+    if (q_stride != 0 && q_stride < 144) return SLK_E_INVALID;
+    a.do_predict = 1; a.pm = model; a.u_stride = u_stride; a.q_stride = q_stride;
+    int rc = stage_in(f, f->st_u, u, u_stride ? (size_t)f->B * u_stride : (size_t)nu, where, &a.u);
+    if (rc) return rc;
+    return stage_in(f, f->st_Q, Q, q_stride ? (size_t)f->B * q_stride : (size_t)144, where, &a.Q);
+}
+
+static int fill_update(slk_filter *f, KArgs &a, int model, const double *params, int p_stride,
+                       const double *z, int m, const double *R, int r_stride, int gate, int where)
+{
+    if (m < 1 || m > MAXM || !z || !R) return SLK_E_INVALID;
+    if (r_stride != 0 && r_stride < m * m) return SLK_E_INVALID;
+    if (f->lay.kind == SLK_MSCKF) {
+        if (model != SLK_MM_FEATURE_PROJ && model != SLK_MM_POSE_POSITION && model != SLK_MODEL_EXTERNAL) return SLK_E_INVALID;
+        if (model == SLK_MM_FEATURE_PROJ && (m & 1)) return SLK_E_INVALID;
+        if (model == SLK_MM_POSE_POSITION && m != 3) return SLK_E_INVALID;
+    } else {
+        if (model != SLK_MM_VO_RELATIVE && model != SLK_MM_FEATURE_PROJ && model != SLK_MM_POSE_POSITION
+            && model != SLK_MODEL_EXTERNAL) return SLK_E_INVALID;
+        if (model == SLK_MM_VO_RELATIVE && (m != f->lay.nfk || m % 3)) return SLK_E_INVALID;
+        if (model == SLK_MM_FEATURE_PROJ && (m & 1)) return SLK_E_INVALID;
+        if (model == SLK_MM_POSE_POSITION && m != 3) return SLK_E_INVALID;
+    }
+    int np = mm_params(model, m);
+    if (np && (!params || (p_stride != 0 && p_stride < np))) return SLK_E_INVALID;
+    a.do_update = 1; a.mm = model; a.m = m; a.gate = gate; a.mp_stride = p_stride; a.r_stride = r_stride;
+    int rc = np ? stage_in(f, f->st_mp, params, p_stride ? (size_t)f->B * p_stride : (size_t)np, where, &a.mp) : SLK_OK;
+    if (rc) return rc;
+    rc = stage_in(f, f->st_z, z, (size_t)f->B * m, where, &a.z);
+    if (rc) return rc;
+    return stage_in(f, f->st_R, R, r_stride ? (size_t)f->B * r_stride : (size_t)m * m, where, &a.R);
+}
+
+static int launch(slk_filter *f, const KArgs &a)
+{
+    return f->lay.kind == SLK_MSCKF ? launch_msckf(f, a) : launch_usckf(f, a);
+}
+
+extern "C" {
+
+int slk_predict(slk_filter *f, int model, const double *u, int u_stride, const double *Q, int q_stride, int where)
+{
+    if (!f) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    KArgs a;
+    base_args(f, a);
+    int rc = fill_predict(f, a, model, u, u_stride, Q, q_stride, where);
+    if (rc) return rc;
+    return launch(f, a);
+}
+
+int slk_update(slk_filter *f, int model, const double *params, int p_stride, const double *z, int m,
+               const double *R, int r_stride, int gate, int where)
+{
+    if (!f || model == SLK_MODEL_EXTERNAL) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    KArgs a;
+    base_args(f, a);
+    int rc = fill_update(f, a, model, params, p_stride, z, m, R, r_stride, gate, where);
+    if (rc) return rc;
+    return launch(f, a);
+}
+
+int slk_step(slk_filter *f, int pmodel, const double *u, int u_stride, const double *Q, int q_stride,
+             int mmodel, const double *params, int p_stride, const double *z, int m,
+             const double *R, int r_stride, int gate, int where)
+{
+    if (!f || mmodel == SLK_MODEL_EXTERNAL) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    KArgs a;
+    base_args(f, a);
+    int rc = fill_predict(f, a, pmodel, u, u_stride, Q, q_stride, where);
+    if (rc) return rc;
+    rc = fill_update(f, a, mmodel, params, p_stride, z, m, R, r_stride, gate, where);
+    if (rc) return rc;
+    return launch(f, a);
+}
+
+int slk_predict_sigma_points(slk_filter *f, double *X, int where)
+{
+    if (!f || !X) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    KArgs a;
+    base_args(f, a);
+    size_t n = (size_t)f->B * 25 * 13;
+    a.emit = 1;
+    if (where == SLK_DEVICE) a.Xout = X;
+    else { int rc = stage_reserve(f, f->st_X, n); if (rc) return rc; a.Xout = f->st_X.p; }
+    int rc = launch(f, a);
+    if (rc) return rc;
+    if (where == SLK_HOST) {
+        HIPCHECK(hipMemcpyAsync(X, a.Xout, n * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+        HIPCHECK(hipStreamSynchronize(f->stream));
+    }
+    return SLK_OK;
+}
+
+int slk_predict_from_sigma(slk_filter *f, const double *Y, const double *Q, int q_stride, int where)
+{
+    if (!f || !Y || !Q) return SLK_E_INVALID;
+    if (q_stride != 0 && q_stride < 144) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    KArgs a;
+    base_args(f, a);
+    a.do_predict = 1; a.pm = SLK_MODEL_EXTERNAL; a.q_stride = q_stride;
+    int rc = stage_in(f, f->st_X, Y, (size_t)f->B * 25 * 13, where, &a.Yext);
+    if (rc) return rc;
+    rc = stage_in(f, f->st_Q, Q, q_stride ? (size_t)f->B * q_stride : (size_t)144, where, &a.Q);
+    if (rc) return rc;
+    return launch(f, a);
+}
+
+int slk_update_sigma_points(slk_filter *f, double *X, int where)
+{
+    if (!f || !X) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    KArgs a;
+    base_args(f, a);
+    size_t n = (size_t)f->B * (2 * f->lay.N + 1) * f->lay.Nq;
+    a.emit = 2; a.m = 1;
+    if (where == SLK_DEVICE) a.Xout = X;
+    else { int rc = stage_reserve(f, f->st_X, n); if (rc) return rc; a.Xout = f->st_X.p; }
+    int rc = launch(f, a);
+    if (rc) return rc;
+    if (where == SLK_HOST) {
+        HIPCHECK(hipMemcpyAsync(X, a.Xout, n * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+        HIPCHECK(hipStreamSynchronize(f->stream));
+    }
+    return SLK_OK;
+}
+
+int slk_update_from_sigma(slk_filter *f, const double *Z, const double *z, int m, const double *R, int r_stride,
+                          int gate, int where)
+{
+    if (!f || !Z) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    KArgs a;
+    base_args(f, a);
+    int rc = fill_update(f, a, SLK_MODEL_EXTERNAL, nullptr, 0, z, m, R, r_stride, gate, where);
+    if (rc) return rc;
+    rc = stage_in(f, f->st_Z, Z, (size_t)f->B * (2 * f->lay.N + 1) * m, where, &a.Zext);
+    if (rc) return rc;
+    return launch(f, a);
+}
+
+int slk_get_outliers(slk_filter *f, unsigned *outliers, int where)
+{
+    if (!f || !outliers) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    HIPCHECK(hipMemcpyAsync(outliers, f->d_outliers, (size_t)f->B * sizeof(unsigned),
+                            where == SLK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, f->stream));
+    if (where == SLK_HOST) HIPCHECK(hipStreamSynchronize(f->stream));
+    return SLK_OK;
+}
+
+int slk_get_status(slk_filter *f, int *status, int where)
+{
+    if (!f || !status) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    HIPCHECK(hipMemcpyAsync(status, f->d_status, (size_t)f->B * sizeof(int),
+                            where == SLK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, f->stream));
+    if (where == SLK_HOST) HIPCHECK(hipStreamSynchronize(f->stream));
+    return SLK_OK;
+}
+
+int slk_clear_status(slk_filter *f)
+{
+    if (!f) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    HIPCHECK(hipMemsetAsync(f->d_status, 0, (size_t)f->B * sizeof(int), f->stream));
+    return SLK_OK;
+}
+
+int slk_sync(slk_filter *f)
+{
+    if (!f) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    HIPCHECK(hipStreamSynchronize(f->stream));
+    return SLK_OK;
+}
+
+int slk_timer_start(slk_filter *f)
+{
+    if (!f) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    HIPCHECK(hipEventRecord(f->ev0, f->stream));
+    return SLK_OK;
+}
+
+int slk_timer_stop(slk_filter *f, float *ms)
+{
+    if (!f || !ms) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    HIPCHECK(hipEventRecord(f->ev1, f->stream));
+    HIPCHECK(hipEventSynchronize(f->ev1));
+    HIPCHECK(hipEventElapsedTime(ms, f->ev0, f->ev1));
+    return SLK_OK;
+}
+
+// ---- Usckf bookkeeping (Usckf.hpp:322-433): block copies on the device
+int slk_usckf_cloning(slk_filter *f, int mode)
+{
+    if (!f || f->lay.kind != SLK_USCKF) return SLK_E_INVALID;
+    if (mode != SLK_STATEK_I && mode != SLK_STATEK_L) return SLK_OK;   // default: break (Usckf.hpp:428-429)
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    int total = f->B * 256;
+    hipLaunchKernelGGL(usckf_cloning_kernel, dim3((total + 255) / 256), dim3(256), 0, f->stream,
+                       f->d_mean, f->d_P, f->B, f->lay.N, f->lay.Nq, mode);
+    HIPCHECK(hipGetLastError());
+    return SLK_OK;
+}
+
+int slk_usckf_set_measurement(slk_filter *f, int mode, const double *z, int n, const double *R, int where)
+{
+    if (!f || f->lay.kind != SLK_USCKF || !z || !R || n < 1) return SLK_E_INVALID;
+    if (mode != SLK_STATEK && mode != SLK_STATEK_L) return SLK_OK;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    Lay oldL = f->lay;
+    int nfk = mode == SLK_STATEK ? n : oldL.nfk, nfkl = mode == SLK_STATEK_L ? n : oldL.nfkl;
+    Lay newL = make_lay(SLK_USCKF, 0, nfk, nfkl);
+    size_t B = (size_t)f->B;
+    const double *dz, *dR;
+    int rc = stage_in(f, f->st_z, z, B * n, where, &dz);
+    if (rc) return rc;
+    rc = stage_in(f, f->st_R, R, (size_t)n * n, where, &dR);
+    if (rc) return rc;
+    // build the new arrays out of place, then swap
+    double *nm = nullptr, *nP = nullptr;
+    HIPCHECK(hipMalloc(&nm, B * newL.Nq * sizeof(double)));
+    HIPCHECK(hipMalloc(&nP, B * (size_t)newL.N * newL.N * sizeof(double)));
+    int total = f->B * newL.N * newL.N;
+    hipLaunchKernelGGL(usckf_set_measurement_kernel, dim3((total + 255) / 256), dim3(256), 0, f->stream,
+                       f->d_mean, f->d_P, nm, nP, dz, dR, f->B, oldL.nfk, oldL.nfkl, nfk, nfkl, mode, n);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(f->stream));
+    HIPCHECK(hipFree(f->d_mean));
+    HIPCHECK(hipFree(f->d_P));
+    f->d_mean = nm; f->d_P = nP;
+    f->cap_mean = newL.Nq; f->cap_P = (size_t)newL.N * newL.N;
+    f->lay = newL;
+    f->cfg.n_featuresk = nfk; f->cfg.n_featuresk_l = nfkl;
+    return SLK_OK;
+}
+
+int slk_msckf_resize(slk_filter *f, int n_clones)
+{
+    if (!f || f->lay.kind != SLK_MSCKF || n_clones < 0) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    Lay newL = make_lay(SLK_MSCKF, n_clones, 0, 0);
+    size_t B = (size_t)f->B;
+    HIPCHECK(hipStreamSynchronize(f->stream));
+    double *nm = nullptr, *nP = nullptr;
+    HIPCHECK(hipMalloc(&nm, B * newL.Nq * sizeof(double)));
+    HIPCHECK(hipMalloc(&nP, B * (size_t)newL.N * newL.N * sizeof(double)));
+    HIPCHECK(hipMemsetAsync(nm, 0, B * newL.Nq * sizeof(double), f->stream));
+    HIPCHECK(hipMemsetAsync(nP, 0, B * (size_t)newL.N * newL.N * sizeof(double), f->stream));
+    HIPCHECK(hipStreamSynchronize(f->stream));
+    HIPCHECK(hipFree(f->d_mean));
+    HIPCHECK(hipFree(f->d_P));
+    f->d_mean = nm; f->d_P = nP;
+    f->lay = newL;
+    f->cfg.n_clones = n_clones;
+    return SLK_OK;
+}
+
+int slk_selftest_mfma(int device)
+{
+    if (slk_device_count() <= 0) { g_err = "no HIP device"; return SLK_E_NO_DEVICE; }
+    HIPCHECK(hipSetDevice(device));
+    double hA[64], hB[64], hC[256], *dA, *dB, *dC;
+    for (int i = 0; i < 64; ++i) { hA[i] = 1.0 + 0.37 * i - 0.01 * i * i; hB[i] = -2.0 + 0.11 * i + 0.003 * i * i; }
+    HIPCHECK(hipMalloc(&dA, sizeof(hA)));
+    HIPCHECK(hipMalloc(&dB, sizeof(hB)));
+    HIPCHECK(hipMalloc(&dC, sizeof(hC)));
+    HIPCHECK(hipMemcpy(dA, hA, sizeof(hA), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dB, hB, sizeof(hB), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(selftest_mfma_kernel, dim3(1), dim3(64), 0, 0, dA, dB, dC);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpy(hC, dC, sizeof(hC), hipMemcpyDeviceToHost));
+    (void)hipFree(dA); hipFree(dB); hipFree(dC);
+    int bad = 0;
+    for (int r = 0; r < 16; ++r)
+        for (int c = 0; c < 16; ++c) {
+            double ref = 0;
+            for (int k = 0; k < 4; ++k) ref += hA[r * 4 + k] * hB[k * 16 + c];
+            double err = hC[r * 16 + c] - ref;
+            if (err < 0) err = -err;
+            if (err > 1e-9) ++bad;
+        }
+    return bad;
+}
+
+} // extern "C"

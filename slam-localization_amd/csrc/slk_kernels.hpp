@@ -1,0 +1,691 @@
+// slk_kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4) for the sigma-point Kalman
+// hot path of localization::Msckf / localization::Usckf (reference src/filters/Msckf.hpp,
+// Usckf.hpp).  One workgroup owns one filter; the filter's covariance lives in LDS for the
+// whole step (Cholesky -> sigma points -> measurement map -> moments -> gain -> downdate ->
+// second Cholesky -> manifold mean -> fp64 MFMA covariance rebuild), HBM sees each of
+// {mean, P} once in and once out.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/slk.h"
+#include "slk_math.hpp"
+
+namespace slk {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int KP = 32;       // sigma points per rebuild panel (8 MFMA k-steps)
+constexpr int MAXM = 32;     // max measurement rows handled on chip
+constexpr int PRED_SCRATCH = 1280;  // doubles of pool used by the 12-DOF predict phase
+
+struct Lay { int kind, k, nfk, nfkl, N, Nq, nso3; };
+
+struct KArgs {
+    int B;
+    Lay lay;
+    double *mean; double *P; int *status; unsigned *outliers;
+    // predict
+    int do_predict, pm; const double *u; int u_stride; const double *Q; int q_stride; const double *Yext;
+    // update
+    int do_update, mm; const double *mp; int mp_stride; const double *z; int m;
+    const double *R; int r_stride; int gate; const double *Zext;
+    // tier B sigma-point emission: 1 = predict sigma points, 2 = update sigma points
+    int emit; double *Xout;
+};
+
+// ------------------------------------------------------------------ layout helpers
+// State.hpp:141-149, :246-252, :384-396 (MultiState tangent order), :567-588 (AugmentedState)
+__host__ __device__ __forceinline__ int so3_toff(const Lay &L, int b)
+{
+    return L.kind == SLK_MSCKF ? (b == 0 ? 3 : 12 + 6 * (b - 1) + 3) : 12 * b + 3;
+}
+__host__ __device__ __forceinline__ int so3_soff(const Lay &L, int b)
+{
+    return L.kind == SLK_MSCKF ? (b == 0 ? 3 : 13 + 7 * (b - 1) + 3) : 13 * b + 3;
+}
+// tangent index -> storage index of a vector component, or -1 with (blk, comp) of an SO(3) block
+__host__ __device__ __forceinline__ int t2s(const Lay &L, int t, int &blk, int &comp)
+{
+    if (L.kind == SLK_MSCKF) {
+        if (t < 12) {
+            if (t < 3) return t;
+            if (t < 6) { blk = 0; comp = t - 3; return -1; }
+            return t + 1;
+        }
+        int c = (t - 12) / 6, r = (t - 12) % 6;
+        if (r < 3) return 13 + 7 * c + r;
+        blk = c + 1; comp = r - 3;
+        return -1;
+    }
+    if (t < 36) {
+        int s = t / 12, r = t % 12;
+        if (r < 3) return 13 * s + r;
+        if (r < 6) { blk = s; comp = r - 3; return -1; }
+        return 13 * s + r + 1;
+    }
+    return 39 + (t - 36);
+}
+// pose index of a measurement model -> tangent offset, storage offset, SO(3) block
+__host__ __device__ __forceinline__ void pose_of(const Lay &L, int c, int &tp, int &sp, int &b)
+{
+    if (L.kind == SLK_MSCKF) {
+        if (c == 0) { tp = 0; sp = 0; b = 0; }
+        else { tp = 12 + 6 * (c - 1); sp = 13 + 7 * (c - 1); b = c; }
+    } else { tp = 12 * c; sp = 13 * c; b = c; }
+}
+
+// ------------------------------------------------------------------ LDS carve (in doubles)
+struct Carve { int A, pdiag, mu, ref, delta, md, small, pool, total; int lda, S, SP, LDD; };
+
+__host__ __device__ inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
+
+__host__ __device__ inline Carve carve_step(int N, int Nq, int m, int nso3, int NT)
+{
+    Carve c;
+    c.lda = N | 1;
+    c.S = 2 * N + 1;
+    c.SP = c.S;                                  // odd row stride of the rotation-row store
+    c.LDD = 16 * NT + ((NT & 1) ? 0 : 16);       // LDD % 32 == 16: the two 16-lane halves of a b64 read hit disjoint banks
+    int o = 0;
+    c.A = o;      o += round_up(N * c.lda, 2);
+    c.pdiag = o;  o += round_up(N, 2);
+    c.mu = o;     o += round_up(Nq, 2);
+    c.ref = o;    o += round_up(Nq, 2);
+    c.delta = o;  o += round_up(N, 2);
+    c.md = o;     o += round_up(N, 2);
+    c.small = o;  o += 64;
+    c.pool = o;
+    int upd1 = round_up(c.S * m, 2) + 3 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (2 * m + 1), 2) + 4 * round_up(m, 2);
+    int upd2 = round_up(3 * nso3 * c.SP, 2) + KP * c.LDD;
+    int pool = PRED_SCRATCH;
+    if (upd1 > pool) pool = upd1;
+    if (upd2 > pool) pool = upd2;
+    c.total = o + pool;
+    return c;
+}
+
+// ------------------------------------------------------------------ implicit sigma points
+// generateSigmaPoints (Msckf.hpp:407-431 / :442-468): X0 = mu + delta, X(2j+1) = mu + (delta + L.col(j)),
+// X(2j+2) = mu + (delta - L.col(j)).  L is the lower triangle of the in-place factor; the strict
+// upper triangle of the array holds other data and must read as 0.
+struct Sig { int j; double sgn; };
+__device__ __forceinline__ Sig sig_of(int i)
+{
+    Sig s;
+    s.j = (i > 0) ? ((i - 1) >> 1) : 0;
+    s.sgn = (i == 0) ? 0.0 : ((i & 1) ? 1.0 : -1.0);
+    return s;
+}
+__device__ __forceinline__ double Lz(const double *A, int lda, int t, int j)
+{
+    return (j <= t) ? A[t + j * lda] : 0.0;
+}
+__device__ __forceinline__ double pert(const double *A, int lda, const double *delta, int t, const Sig &s)
+{
+    double l = (s.sgn != 0.0) ? s.sgn * Lz(A, lda, t, s.j) : 0.0;
+    return delta ? (delta[t] + l) : l;
+}
+__device__ __forceinline__ Quat sigma_quat(const Lay &L, const double *mu, const double *A, int lda,
+                                           const double *delta, int b, const Sig &s)
+{
+    int to = so3_toff(L, b);
+    return qmul(ldq(mu + so3_soff(L, b)),
+                so3_exp(pert(A, lda, delta, to, s), pert(A, lda, delta, to + 1, s), pert(A, lda, delta, to + 2, s)));
+}
+
+// ------------------------------------------------------------------ in-place lower Cholesky in LDS
+// Right-looking; only the lower triangle is read or written (the strict upper triangle keeps
+// whatever the caller stored there).  Returns -1, or the first non-positive pivot (same value in
+// every thread).  Eigen::LLT in the reference never has its info() read (Msckf.hpp:412-413).
+template <int NTHREADS>
+__device__ int chol_lower_inplace(double *A, int n, int lda, int tid)
+{
+    constexpr int NW = NTHREADS / 64;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int k = 0; k < n; ++k) {
+        double d = A[k + k * lda];
+        if (!(d > 0.0)) return k;
+        double s = sqrt(d);
+        for (int i = k + 1 + tid; i < n; i += NTHREADS) A[i + k * lda] = A[i + k * lda] / s;
+        __syncthreads();
+        for (int j = k + 1 + wave; j < n; j += NW) {
+            double ljk = A[j + k * lda];
+            for (int i = j + lane; i < n; i += 64) A[i + j * lda] -= A[i + k * lda] * ljk;
+        }
+        if (tid == 0) A[k + k * lda] = s;
+        __syncthreads();
+    }
+    return -1;
+}
+
+// ------------------------------------------------------------------ registered measurement models
+// one work item = (sigma point i, feature f); writes that feature's rows of Z[i*m + ...]
+__device__ __forceinline__ void measure_item(const KArgs &a, const Lay &L, const double *mp, const double *mu,
+                                             const double *A, int lda, int i, int f, double *Zrow)
+{
+    Sig s = sig_of(i);
+    if (a.mm == SLK_MM_FEATURE_PROJ) {
+        int tp, sp, b;
+        pose_of(L, (int)mp[4 * f + 3], tp, sp, b);
+        double px = mu[sp] + pert(A, lda, nullptr, tp, s);
+        double py = mu[sp + 1] + pert(A, lda, nullptr, tp + 1, s);
+        double pz = mu[sp + 2] + pert(A, lda, nullptr, tp + 2, s);
+        Quat q = sigma_quat(L, mu, A, lda, nullptr, b, s);
+        double lx, ly, lz;
+        qrot(qconj(q), mp[4 * f] - px, mp[4 * f + 1] - py, mp[4 * f + 2] - pz, lx, ly, lz);
+        Zrow[2 * f] = lx / lz;
+        Zrow[2 * f + 1] = ly / lz;
+    } else if (a.mm == SLK_MM_POSE_POSITION) {
+        int tp, sp, b;
+        pose_of(L, (int)mp[0], tp, sp, b);
+        for (int c = 0; c < 3 && c < a.m; ++c) Zrow[c] = mu[sp + c] + pert(A, lda, nullptr, tp + c, s);
+    } else { // SLK_MM_VO_RELATIVE (Usckf layout): UsckfUnitTest.cpp:62-86, feature triple f
+        double dk[3], di[3];
+        for (int c = 0; c < 3; ++c) {
+            dk[c] = mu[c] + pert(A, lda, nullptr, c, s);
+            di[c] = mu[26 + c] + pert(A, lda, nullptr, 24 + c, s);
+        }
+        Quat qk = sigma_quat(L, mu, A, lda, nullptr, 0, s), qi = sigma_quat(L, mu, A, lda, nullptr, 2, s);
+        double rx, ry, rz;
+        so3_boxminus(qk, qi, rx, ry, rz);               // delta_state = statek - statek_i
+        Quat dq = so3_exp(rx, ry, rz);                  // ... assigned to a WSingleState: set()
+        double fx = mu[39 + 3 * f] + pert(A, lda, nullptr, 36 + 3 * f, s);
+        double fy = mu[39 + 3 * f + 1] + pert(A, lda, nullptr, 36 + 3 * f + 1, s);
+        double fz = mu[39 + 3 * f + 2] + pert(A, lda, nullptr, 36 + 3 * f + 2, s);
+        double ox, oy, oz;
+        qmat_apply(dq, fx, fy, fz, ox, oy, oz);
+        Zrow[3 * f] = ox + (dk[0] - di[0]);
+        Zrow[3 * f + 1] = oy + (dk[1] - di[1]);
+        Zrow[3 * f + 2] = oz + (dk[2] - di[2]);
+    }
+}
+__host__ __device__ __forceinline__ int measure_features(int mm, int m)
+{
+    return mm == SLK_MM_FEATURE_PROJ ? m / 2 : (mm == SLK_MM_POSE_POSITION ? 1 : m / 3);
+}
+
+// ------------------------------------------------------------------ 12-DOF predict phase
+// Msckf.hpp:102-165 == Usckf.hpp:117-181: sigma points of the current State, process model map,
+// manifold mean, new Pk_i = cov + Q.  Pblk = 12x12 (ld 13) lower block of the covariance on entry,
+// Cholesky factor on exit (Usckf needs it for Fk); x13 = current State mean, replaced by the new
+// mean.  Pn (12x12, ld 12) receives the new block.  Returns 0 or status bits (uniform).
+// scratch layout (doubles): Ys[25*13] dbuf[25*12] refs[16] mdel[16]
+template <int NTHREADS, bool WANT_PXY>
+__device__ int predict_phase(const KArgs &a, int bidx, int tid, double *Pblk, double *x13, double *Pn,
+                             double *scr, double *Pxy /* 12x12 ld 12, only if WANT_PXY */)
+{
+    double *Ys = scr, *dbuf = scr + 25 * 13, *refs = dbuf + 25 * 12, *mdel = refs + 16;
+    int fail = chol_lower_inplace<NTHREADS>(Pblk, 12, 13, tid);
+    if (fail >= 0) return SLK_ST_LLT_FAIL;
+    const double *u = a.u ? a.u + (size_t)bidx * a.u_stride : nullptr;
+    if (tid < 25) {
+        Sig s = sig_of(tid);
+        double v[12], x[13], y[13];
+        for (int t = 0; t < 12; ++t) v[t] = pert(Pblk, 13, nullptr, t, s);
+        state_boxplus(x13, v, x);
+        if (a.emit == 1) {
+            for (int c = 0; c < 13; ++c) a.Xout[((size_t)bidx * 25 + tid) * 13 + c] = x[c];
+        } else if (a.pm == SLK_MODEL_EXTERNAL) {
+            for (int c = 0; c < 13; ++c) y[c] = a.Yext[((size_t)bidx * 25 + tid) * 13 + c];
+        } else {
+            process_model(a.pm, u, x, y);
+        }
+        if (a.emit != 1)
+            for (int c = 0; c < 13; ++c) Ys[tid * 13 + c] = y[c];
+    }
+    if (a.emit == 1) return -1;   // sigma points emitted, nothing else to do
+    __syncthreads();
+    if (tid < 13) refs[tid] = Ys[tid];              // reference = X[0]  (Msckf.hpp:473)
+    __syncthreads();
+    int it = 0, status = 0;
+    double norm;
+    do {                                            // Msckf.hpp:478-487
+        if (tid < 25) state_boxminus(Ys + tid * 13, refs, dbuf + tid * 12);
+        __syncthreads();
+        if (tid < 12) {
+            double sum = 0.0;
+            for (int i = 0; i < 25; ++i) sum += dbuf[i * 12 + tid];
+            mdel[tid] = sum / 25.0;
+        }
+        __syncthreads();
+        double n2 = 0.0;
+        for (int t = 0; t < 12; ++t) n2 += mdel[t] * mdel[t];
+        norm = sqrt(n2);
+        if (tid == 0) {
+            double nr[13];
+            state_boxplus(refs, mdel, nr);
+            for (int c = 0; c < 13; ++c) refs[c] = nr[c];
+        }
+        __syncthreads();
+    } while (norm > 1e-6 && ++it < 10000);
+    if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
+    // covariance (Msckf.hpp:554-570) + Q (:162)
+    if (tid < 25) state_boxminus(Ys + tid * 13, refs, dbuf + tid * 12);
+    __syncthreads();
+    const double *Q = a.Q + (size_t)bidx * a.q_stride;
+    for (int e = tid; e < 144; e += NTHREADS) {
+        int r = e % 12, c = e / 12;
+        double sum = 0.0;
+        for (int i = 0; i < 25; ++i) sum += dbuf[i * 12 + r] * dbuf[i * 12 + c];
+        Pn[e] = 0.5 * sum + Q[e];
+        if (WANT_PXY) {
+            // Pxy = 1/2 sum (XCopy_i [-] mu_old)(X_i [-] mu_new)^T, XCopy_i [-] mu_old = +-L.col(j)
+            // (Usckf.hpp:152-153, :691-712)
+            double sx = 0.0;
+            for (int i = 1; i < 25; ++i) {
+                Sig s = sig_of(i);
+                sx += s.sgn * Lz(Pblk, 13, r, s.j) * dbuf[i * 12 + c];
+            }
+            Pxy[e] = 0.5 * sx;
+        }
+    }
+    __syncthreads();
+    if (tid < 13) x13[tid] = refs[tid];
+    __syncthreads();
+    return status;
+}
+
+// ------------------------------------------------------------------ fp64 MFMA covariance rebuild
+// P+ = 1/2 * D * D^T (Msckf.hpp:574-589), D = N x S deviations streamed through LDS in panels of KP
+// sigma points.  v_mfma_f64_16x16x4_f64: lane l holds A[row l&15][k l>>4] and B[k l>>4][col l&15];
+// for D*D^T the A fragment of row-tile I equals the B fragment of column-tile I.  Result lane l,
+// register r: row (l>>4)+4r, col l&15.  Lower-triangle tiles only, dealt round-robin to the waves.
+template <int NT> struct TileMap {
+    static constexpr int NTILES = NT * (NT + 1) / 2;
+    __host__ __device__ static constexpr int row(int t) { int i = 0; while ((i + 1) * (i + 2) / 2 <= t) ++i; return i; }
+    __host__ __device__ static constexpr int col(int t) { return t - row(t) * (row(t) + 1) / 2; }
+};
+
+template <int NT, int NW, int T>
+struct MfmaTiles {
+    static constexpr int TPW = (TileMap<NT>::NTILES + NW - 1) / NW;
+    __device__ __forceinline__ static void run(const double (&frag)[NT], d4 (&acc)[TPW], int wave)
+    {
+        if constexpr (T < TileMap<NT>::NTILES) {
+            if ((T % NW) == wave)
+                acc[T / NW] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[TileMap<NT>::row(T)], frag[TileMap<NT>::col(T)],
+                                                                 acc[T / NW], 0, 0, 0);
+            MfmaTiles<NT, NW, T + 1>::run(frag, acc, wave);
+        }
+    }
+    __device__ __forceinline__ static void store(double *A, int lda, int N, const d4 (&acc)[TPW], int wave, int lane)
+    {
+        if constexpr (T < TileMap<NT>::NTILES) {
+            if ((T % NW) == wave) {
+                constexpr int I = TileMap<NT>::row(T), J = TileMap<NT>::col(T);
+                int c = 16 * J + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int rr = 16 * I + (lane >> 4) + 4 * r;
+                    if (rr < N && c < N) {
+                        double v = 0.5 * acc[T / NW][r];
+                        A[rr + c * lda] = v;
+                        if (I != J) A[c + rr * lda] = v;
+                    }
+                }
+            }
+            MfmaTiles<NT, NW, T + 1>::store(A, lda, N, acc, wave, lane);
+        }
+    }
+};
+
+// ------------------------------------------------------------------ the Msckf step kernel
+// predict (optional) + UKF update with applyDelta (optional), one workgroup per filter.
+template <int NT, int NTHREADS>
+__global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NW = NTHREADS / 64;
+    const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Lay L = a.lay;
+    const int N = L.N, Nq = L.Nq, m = a.m, nso3 = L.nso3;
+    const Carve cv = carve_step(N, Nq, m, nso3, NT);
+    const int lda = cv.lda, S = cv.S, SP = cv.SP, LDD = cv.LDD;
+    double *A = smem + cv.A, *pdiag = smem + cv.pdiag, *mu = smem + cv.mu, *ref = smem + cv.ref;
+    double *delta = smem + cv.delta, *md = smem + cv.md, *pool = smem + cv.pool;
+    int *ish = reinterpret_cast<int *>(smem + cv.small);      // [0..MAXM) idx, [40] count, [41] outliers, [42] flag
+    double *gmean = a.mean + (size_t)bidx * Nq;
+    double *gP = a.P + (size_t)bidx * N * N;
+    int status = 0;
+    if (a.do_update && tid == 0) a.outliers[bidx] = 0u;
+
+    // ---- load: mean, and the LOWER triangle of P mirrored into both triangles (only the lower
+    // triangle of Pk is ever read by Msckf::predict/update: LLT at :412, :447; the rebuild overwrites all)
+    for (int e = tid; e < Nq; e += NTHREADS) mu[e] = gmean[e];
+    if (a.do_update || a.emit == 2) {
+        for (int e = tid; e < N * N; e += NTHREADS) {
+            int r = e % N, c = e / N;
+            if (r >= c) {
+                double v = gP[e];
+                A[r + c * lda] = v;
+                A[c + r * lda] = v;
+                if (r == c) pdiag[r] = v;
+            }
+        }
+    } else {
+        for (int e = tid; e < 144; e += NTHREADS) {
+            int r = e % 12, c = e / 12;
+            if (r >= c) { double v = gP[r + (size_t)c * N]; A[r + c * lda] = v; A[c + r * lda] = v; }
+        }
+    }
+    __syncthreads();
+
+    // ---- predict: Msckf.hpp:89-189 (state<->clone cross-covariances stay stale: :171-182)
+    if (a.do_predict || a.emit == 1) {
+        double *Pblk = pool, *Pn = pool + 160, *scr = pool + 320;   // 156 + 144 + (325+300+32)
+        for (int e = tid; e < 144; e += NTHREADS) { int r = e % 12, c = e / 12; Pblk[r + c * 13] = A[r + c * lda]; }
+        __syncthreads();
+        int st = predict_phase<NTHREADS, false>(a, bidx, tid, Pblk, mu, Pn, scr, nullptr);
+        if (a.emit == 1) return;
+        if (st & SLK_ST_LLT_FAIL) {
+            status |= st;                       // predict skipped, filter unchanged
+        } else {
+            status |= st;
+            for (int e = tid; e < 144; e += NTHREADS) {
+                int r = e % 12, c = e / 12;
+                gP[r + (size_t)c * N] = Pn[e];
+                double v = (r >= c) ? Pn[e] : Pn[c + 12 * r];    // on chip: lower triangle mirrored
+                A[r + c * lda] = v;
+                if (r == c) pdiag[r] = v;
+            }
+            for (int e = tid; e < 13; e += NTHREADS) gmean[e] = mu[e];
+        }
+        __syncthreads();
+    }
+
+    if (a.do_update || a.emit == 2) {
+        // ---- sigma points of the full state: Msckf.hpp:228-229 -> :400-431
+        int fail = chol_lower_inplace<NTHREADS>(A, N, lda, tid);
+        if (fail >= 0) {
+            status |= SLK_ST_LLT_FAIL;
+        } else if (a.emit == 2) {
+            double *X = a.Xout + (size_t)bidx * S * Nq;
+            for (int e = tid; e < S * N; e += NTHREADS) {
+                int t = e % N, i = e / N, blk = 0, comp = 0;
+                int s = t2s(L, t, blk, comp);
+                if (s >= 0) X[(size_t)i * Nq + s] = mu[s] + pert(A, lda, nullptr, t, sig_of(i));
+            }
+            for (int e = tid; e < S * nso3; e += NTHREADS) {
+                int b = e % nso3, i = e / nso3;
+                Quat q = sigma_quat(L, mu, A, lda, nullptr, b, sig_of(i));
+                double *o = X + (size_t)i * Nq + so3_soff(L, b);
+                o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
+            }
+        } else {
+            // ---- pool carve for the measurement part
+            double *Z = pool;                                   // [S][m]
+            double *Pxz = Z + round_up(S * m, 2);               // N x m (ld N)
+            double *K = Pxz + round_up(N * m, 2);
+            double *KS = K + round_up(N * m, 2);
+            double *Sm = KS + round_up(N * m, 2);               // m x m (ld m)
+            double *G = Sm + round_up(m * m, 2);                // m x (2m+1) row-major Gauss-Jordan tableau
+            double *zbar = G + round_up(m * (2 * m + 1), 2);
+            double *innov = zbar + round_up(m, 2);
+            int *idx = ish;
+            const double *mp = a.mp ? a.mp + (size_t)bidx * a.mp_stride : nullptr;
+
+            // Z = h(X): Msckf.hpp:231-232
+            if (a.mm == SLK_MODEL_EXTERNAL) {
+                const double *Ze = a.Zext + (size_t)bidx * S * m;
+                for (int e = tid; e < S * m; e += NTHREADS) Z[e] = Ze[e];
+            } else {
+                int nf = measure_features(a.mm, m);
+                for (int e = tid; e < S * nf; e += NTHREADS) {
+                    int f = e % nf, i = e / nf;
+                    measure_item(a, L, mp, mu, A, lda, i, f, Z + i * m);
+                }
+            }
+            __syncthreads();
+            // mean_z (:234, accumulate then divide), innovation (:236)
+            for (int r = tid; r < m; r += NTHREADS) {
+                double sum = 0.0;
+                for (int i = 0; i < S; ++i) sum += Z[i * m + r];
+                double zb = sum / (double)S;
+                zbar[r] = zb;
+                innov[r] = a.z[(size_t)bidx * m + r] - zb;
+            }
+            __syncthreads();
+            // S = cov(Z) + R (:238), covXZ (:239 -> :635-657).  X_i [-] mu = +-L.col(j) (and 0 for X_0):
+            // covXZ = 1/2 L * (Z_{2j+1} - Z_{2j+2})_j ; exact while every rotation column is shorter than pi.
+            const double *R = a.R + (size_t)bidx * a.r_stride;
+            for (int e = tid; e < m * m; e += NTHREADS) {
+                int r = e % m, c = e / m;
+                double zr = zbar[r], zc = zbar[c], sum = 0.0;
+                for (int i = 0; i < S; ++i) sum += (Z[i * m + r] - zr) * (Z[i * m + c] - zc);
+                Sm[e] = 0.5 * sum + R[e];
+            }
+            for (int e = tid; e < N * m; e += NTHREADS) {
+                int t = e % N, r = e / N, blk = -1, comp = 0;
+                int s = t2s(L, t, blk, comp);
+                double sum = 0.0;
+                if (s >= 0) {
+                    for (int j = 0; j <= t; ++j) sum += A[t + j * lda] * (Z[(2 * j + 1) * m + r] - Z[(2 * j + 2) * m + r]);
+                } else {
+                    // rotation rows: log(exp(v)) wraps once |v| >= pi (MTK log uses atan): scale the column
+                    int t0 = t - comp;
+                    for (int j = 0; j <= t; ++j) {
+                        double v0 = Lz(A, lda, t0, j), v1 = Lz(A, lda, t0 + 1, j), v2 = Lz(A, lda, t0 + 2, j);
+                        double th = sqrt(v0 * v0 + v1 * v1 + v2 * v2), w = 1.0;
+                        if (th >= 3.141592653589793) w = 2.0 * atan(tan(0.5 * th)) / th;
+                        sum += w * A[t + j * lda] * (Z[(2 * j + 1) * m + r] - Z[(2 * j + 2) * m + r]);
+                    }
+                }
+                Pxz[e] = 0.5 * sum;
+            }
+            __syncthreads();
+            // removeOutliers (:241 -> :723-754) incl. the shifted second erase (:741-744)
+            if (tid == 0) {
+                int cnt = m;
+                unsigned nout = 0;
+                for (int r = 0; r < m; ++r) idx[r] = r;
+                int i = 0;
+                while (i < cnt / 2) {
+                    int p = idx[2 * i], q = idx[2 * i + 1];
+                    double s00 = Sm[p + m * p], s01 = Sm[p + m * q], s10 = Sm[q + m * p], s11 = Sm[q + m * q];
+                    double det = s00 * s11 - s01 * s10, r0 = innov[p], r1 = innov[q];
+                    double d2 = (r0 * (s11 * r0 - s01 * r1) + r1 * (s00 * r1 - s10 * r0)) / det;
+                    bool ok = a.gate ? (d2 < 5.99) : true;            // chi2_0.95(2), Msckf.hpp:861-865
+                    if (!ok) {
+                        for (int rep = 0; rep < 2; ++rep) {           // removeRow semantics, :688-697
+                            int pos = 2 * i + rep, numRows = cnt - 1;
+                            if (pos < numRows) for (int w = pos; w < numRows; ++w) idx[w] = idx[w + 1];
+                            cnt = numRows;
+                        }
+                        nout++;
+                    } else {
+                        i++;
+                    }
+                }
+                ish[40] = cnt;
+                ish[41] = (int)nout;
+                ish[42] = 0;
+            }
+            __syncthreads();
+            const int mmr = ish[40];
+            if (tid == 0) a.outliers[bidx] = (unsigned)ish[41];
+            if (mmr == 0) {
+                status |= SLK_ST_ALL_REJECTED;                         // :250, nothing applied
+            } else {
+                // S^-1 by Gauss-Jordan with partial pivoting (reference: Eigen PartialPivLU inverse, :257)
+                const int ldg = 2 * mmr + 1;
+                for (int e = tid; e < mmr * mmr; e += NTHREADS) {
+                    int r = e % mmr, c = e / mmr;
+                    G[r * ldg + c] = Sm[idx[r] + m * idx[c]];
+                    G[r * ldg + mmr + c] = (r == c) ? 1.0 : 0.0;
+                }
+                __syncthreads();
+                bool singular = false;
+                for (int k = 0; k < mmr; ++k) {
+                    int piv = k;
+                    double best = fabs(G[k * ldg + k]);
+                    for (int i = k + 1; i < mmr; ++i) {
+                        double v = fabs(G[i * ldg + k]);
+                        if (v > best) { best = v; piv = i; }
+                    }
+                    if (!(best > 0.0)) { singular = true; break; }
+                    __syncthreads();
+                    if (piv != k)
+                        for (int c = tid; c < 2 * mmr; c += NTHREADS) {
+                            double t0 = G[k * ldg + c]; G[k * ldg + c] = G[piv * ldg + c]; G[piv * ldg + c] = t0;
+                        }
+                    __syncthreads();
+                    double pv = G[k * ldg + k];
+                    __syncthreads();
+                    for (int c = tid; c < 2 * mmr; c += NTHREADS) G[k * ldg + c] = G[k * ldg + c] / pv;
+                    __syncthreads();
+                    for (int r = tid; r < mmr; r += NTHREADS) {
+                        if (r == k) continue;
+                        double f = G[r * ldg + k];
+                        for (int c = 0; c < 2 * mmr; ++c) G[r * ldg + c] -= f * G[k * ldg + c];
+                    }
+                    __syncthreads();
+                }
+                if (singular) {
+                    status |= SLK_ST_SINGULAR;
+                } else {
+                    // K = covXZ * S^-1 (:257)
+                    for (int e = tid; e < N * mmr; e += NTHREADS) {
+                        int t = e % N, c = e / N;
+                        double sum = 0.0;
+                        for (int c2 = 0; c2 < mmr; ++c2) sum += Pxz[t + N * idx[c2]] * G[c2 * ldg + mmr + c];
+                        K[e] = sum;
+                    }
+                    __syncthreads();
+                    // delta = K * innovation (:263), KS = K * S
+                    for (int e = tid; e < N * mmr; e += NTHREADS) {
+                        int t = e % N, c = e / N;
+                        double sum = 0.0;
+                        for (int c2 = 0; c2 < mmr; ++c2) sum += K[t + N * c2] * Sm[idx[c2] + m * idx[c]];
+                        KS[e] = sum;
+                    }
+                    for (int t = tid; t < N; t += NTHREADS) {
+                        double sum = 0.0;
+                        for (int c = 0; c < mmr; ++c) sum += K[t + N * c] * innov[idx[c]];
+                        delta[t] = sum;
+                    }
+                    __syncthreads();
+                    // Pk -= K S K^T (:262), lower triangle; P itself = strict upper triangle + pdiag
+                    for (int j = wave; j < N; j += NW)
+                        for (int i = j + lane; i < N; i += 64) {
+                            double p = (i == j) ? pdiag[i] : A[j + i * lda];
+                            double sum = 0.0;
+                            for (int c = 0; c < mmr; ++c) sum += KS[i + N * c] * K[j + N * c];
+                            A[i + j * lda] = p - sum;
+                        }
+                    __syncthreads();
+                    // ---- applyDelta (:263 -> :659-666): second Cholesky, re-drawn sigma points
+                    fail = chol_lower_inplace<NTHREADS>(A, N, lda, tid);
+                    if (fail >= 0) {
+                        status |= SLK_ST_LLT_FAIL;
+                    } else {
+                        double *Drot = pool;                              // [3*nso3][SP] rotation rows of X_i [-] ref
+                        double *Dp = pool + round_up(3 * nso3 * SP, 2);   // [KP][LDD] panel
+                        // reference = X[0] = mu + delta (:501)
+                        for (int t = tid; t < N; t += NTHREADS) {
+                            int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
+                            if (s >= 0) ref[s] = mu[s] + delta[t];
+                        }
+                        for (int b = tid; b < nso3; b += NTHREADS)
+                            stq(ref + so3_soff(L, b), sigma_quat(L, mu, A, lda, delta, b, sig_of(0)));
+                        __syncthreads();
+                        int it = 0;
+                        double norm;
+                        do {                                              // :507-516
+                            for (int e = tid; e < S * nso3; e += NTHREADS) {
+                                int i = e % S, b = e / S;
+                                Quat q = sigma_quat(L, mu, A, lda, delta, b, sig_of(i));
+                                double dx, dy, dz;
+                                so3_boxminus(q, ldq(ref + so3_soff(L, b)), dx, dy, dz);
+                                Drot[(3 * b) * SP + i] = dx;
+                                Drot[(3 * b + 1) * SP + i] = dy;
+                                Drot[(3 * b + 2) * SP + i] = dz;
+                            }
+                            __syncthreads();
+                            for (int t = tid; t < N; t += NTHREADS) {
+                                int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
+                                double sum = 0.0;
+                                if (s >= 0) {
+                                    double m0 = mu[s], r0 = ref[s];
+                                    for (int i = 0; i < S; ++i) sum += (m0 + pert(A, lda, delta, t, sig_of(i))) - r0;
+                                } else {
+                                    const double *row = Drot + (3 * blk + comp) * SP;
+                                    for (int i = 0; i < S; ++i) sum += row[i];
+                                }
+                                md[t] = sum / (double)S;
+                            }
+                            __syncthreads();
+                            double n2 = 0.0;
+                            for (int t = 0; t < N; ++t) n2 += md[t] * md[t];
+                            norm = sqrt(n2);
+                            for (int t = tid; t < N; t += NTHREADS) {       // reference += mean_delta
+                                int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
+                                if (s >= 0) ref[s] = ref[s] + md[t];
+                            }
+                            for (int b = tid; b < nso3; b += NTHREADS) {
+                                int to = so3_toff(L, b), so = so3_soff(L, b);
+                                stq(ref + so, qmul(ldq(ref + so), so3_exp(md[to], md[to + 1], md[to + 2])));
+                            }
+                            __syncthreads();
+                        } while (norm > 1e-6 && ++it < 10000);
+                        if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
+                        // rotation rows of D = X_i [-] mu+ (:584)
+                        for (int e = tid; e < S * nso3; e += NTHREADS) {
+                            int i = e % S, b = e / S;
+                            Quat q = sigma_quat(L, mu, A, lda, delta, b, sig_of(i));
+                            double dx, dy, dz;
+                            so3_boxminus(q, ldq(ref + so3_soff(L, b)), dx, dy, dz);
+                            Drot[(3 * b) * SP + i] = dx;
+                            Drot[(3 * b + 1) * SP + i] = dy;
+                            Drot[(3 * b + 2) * SP + i] = dz;
+                        }
+                        __syncthreads();
+                        // P+ = 1/2 D D^T on the fp64 matrix cores
+                        constexpr int TN = 16 * NT;
+                        constexpr int TPW = MfmaTiles<NT, NW, 0>::TPW;
+                        d4 acc[TPW];
+#pragma unroll
+                        for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+                        for (int p0 = 0; p0 < S; p0 += KP) {
+                            for (int e = tid; e < KP * TN; e += NTHREADS) {
+                                int t = e % TN, kk = e / TN, i = p0 + kk;
+                                double v = 0.0;
+                                if (t < N && i < S) {
+                                    int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
+                                    if (s >= 0) v = (mu[s] + pert(A, lda, delta, t, sig_of(i))) - ref[s];
+                                    else v = Drot[(3 * blk + comp) * SP + i];
+                                }
+                                Dp[kk * LDD + t] = v;
+                            }
+                            __syncthreads();
+#pragma unroll
+                            for (int ks = 0; ks < KP / 4; ++ks) {
+                                double frag[NT];
+#pragma unroll
+                                for (int I = 0; I < NT; ++I) frag[I] = Dp[(4 * ks + (lane >> 4)) * LDD + 16 * I + (lane & 15)];
+                                MfmaTiles<NT, NW, 0>::run(frag, acc, wave);
+                            }
+                            __syncthreads();
+                        }
+                        MfmaTiles<NT, NW, 0>::store(A, lda, N, acc, wave, lane);
+                        __syncthreads();
+                        for (int e = tid; e < N * N; e += NTHREADS) { int r = e % N, c = e / N; gP[e] = A[r + c * lda]; }
+                        for (int e = tid; e < Nq; e += NTHREADS) gmean[e] = ref[e];
+                    }
+                }
+            }
+        }
+    }
+    if (tid == 0 && status) atomicOr(a.status + bidx, status);
+}
+
+// ------------------------------------------------------------------ MFMA fragment layout self test
+__global__ void selftest_mfma_kernel(const double *Amat /*16x4 row-major*/, const double *Bmat /*4x16 row-major*/,
+                                     double *C /*16x16 row-major*/)
+{
+    int l = threadIdx.x;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Amat[(l & 15) * 4 + (l >> 4)], Bmat[(l >> 4) * 16 + (l & 15)], acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) C[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
+}
+
+} // namespace slk

@@ -1,0 +1,135 @@
+// slk_math.hpp -- device-side manifold arithmetic and the registered models.
+//
+// SO(3) follows MTK::SO3<double> (third-party of the reference, restated from its published
+// algorithm): exp(v) = (sinc(|v|/2)/2 * v, cos(|v|/2)), log(q) = 2 atan(|vec|/w)/|vec| * vec,
+// boxplus q <- q * exp(v), boxminus log(other^-1 * q).  Used by reference
+// src/filters/State.hpp:166-200 (State::set / boxplus / boxminus) and :215-239.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace slk {
+
+struct Quat { double x, y, z, w; };
+
+__device__ __forceinline__ Quat qmul(const Quat &a, const Quat &b)
+{
+    Quat o;
+    o.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    o.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    o.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+    o.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+    return o;
+}
+
+__device__ __forceinline__ Quat qconj(const Quat &q) { return Quat{-q.x, -q.y, -q.z, q.w}; }
+
+// Eigen QuaternionBase::_transformVector: v + w*(2 u x v) + u x (2 u x v)
+__device__ __forceinline__ void qrot(const Quat &q, double vx, double vy, double vz,
+                                     double &ox, double &oy, double &oz)
+{
+    double ux = q.y * vz - q.z * vy, uy = q.z * vx - q.x * vz, uz = q.x * vy - q.y * vx;
+    ux += ux; uy += uy; uz += uz;
+    ox = vx + q.w * ux + (q.y * uz - q.z * uy);
+    oy = vy + q.w * uy + (q.z * ux - q.x * uz);
+    oz = vz + q.w * uz + (q.x * uy - q.y * ux);
+}
+
+// MTK cos_sinc_sqrt(x) = (cos(sqrt x), sin(sqrt x)/sqrt x), Taylor series below eps^(1/4) = 2^-13
+__device__ __forceinline__ void cos_sinc_sqrt(double x, double &c, double &s)
+{
+    if (x >= 1.220703125e-4) {
+        double sx = sqrt(x), sn, cs;
+        sincos(sx, &sn, &cs);
+        c = cs;
+        s = sn / sx;
+    } else {
+        double cosi = 1.0, sinc = 1.0, term = -0.5 * x;
+        cosi += term; term *= (1.0 / 3.0); sinc += term; term *= -(1.0 / 4.0) * x;
+        cosi += term; term *= (1.0 / 5.0); sinc += term; term *= -(1.0 / 6.0) * x;
+        cosi += term; term *= (1.0 / 7.0); sinc += term;
+        c = cosi;
+        s = sinc;
+    }
+}
+
+__device__ __forceinline__ Quat so3_exp(double vx, double vy, double vz)
+{
+    double c, s;
+    cos_sinc_sqrt(0.25 * (vx * vx + vy * vy + vz * vz), c, s);
+    double m = s * 0.5;
+    return Quat{m * vx, m * vy, m * vz, c};
+}
+
+__device__ __forceinline__ void so3_log(const Quat &q, double &vx, double &vy, double &vz)
+{
+    double nv = sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
+    if (nv < 1e-11) nv = 1e-11;
+    double s = 2.0 / nv * atan(nv / q.w);
+    vx = s * q.x; vy = s * q.y; vz = s * q.z;
+}
+
+// other [-] ... : log(b^-1 * a)
+__device__ __forceinline__ void so3_boxminus(const Quat &a, const Quat &b, double &vx, double &vy, double &vz)
+{
+    so3_log(qmul(qconj(b), a), vx, vy, vz);
+}
+
+__device__ __forceinline__ Quat ldq(const double *p) { return Quat{p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ void stq(double *p, const Quat &q) { p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w; }
+
+// ---------------------------------------------------------------- single State (13) helpers
+// x [+] v for one State (State.hpp:186-192); v has 12 entries
+__device__ __forceinline__ void state_boxplus(const double *x, const double *v, double *o)
+{
+    o[0] = x[0] + v[0]; o[1] = x[1] + v[1]; o[2] = x[2] + v[2];
+    stq(o + 3, qmul(ldq(x + 3), so3_exp(v[3], v[4], v[5])));
+    o[7] = x[7] + v[6]; o[8] = x[8] + v[7]; o[9] = x[9] + v[8];
+    o[10] = x[10] + v[9]; o[11] = x[11] + v[10]; o[12] = x[12] + v[11];
+}
+
+// a [-] b for one State (State.hpp:194-200)
+__device__ __forceinline__ void state_boxminus(const double *a, const double *b, double *d)
+{
+    d[0] = a[0] - b[0]; d[1] = a[1] - b[1]; d[2] = a[2] - b[2];
+    so3_boxminus(ldq(a + 3), ldq(b + 3), d[3], d[4], d[5]);
+    d[6] = a[7] - b[7]; d[7] = a[8] - b[8]; d[8] = a[9] - b[9];
+    d[9] = a[10] - b[10]; d[10] = a[11] - b[11]; d[11] = a[12] - b[12];
+}
+
+// ---------------------------------------------------------------- registered process models
+// SLK_PM_CONST_VELOCITY: test/UsckfUnitTest.cpp:34-49;  u = v[3] w[3] dt
+// SLK_PM_DELTA_POSE:     test/MsckfUnitTest.cpp:33-47;  u = dpos[3] dquat[4] v[3] w[3]
+__device__ __forceinline__ void process_model(int model, const double *u, const double *x, double *y)
+{
+    if (model == 1) {
+        double dt = u[6];
+        Quat rot = so3_exp(u[3] * dt, u[4] * dt, u[5] * dt);
+        stq(y + 3, qmul(ldq(x + 3), rot));
+        y[10] = u[3]; y[11] = u[4]; y[12] = u[5];
+        y[7] = u[0]; y[8] = u[1]; y[9] = u[2];
+        y[0] = x[0] + x[7] * dt; y[1] = x[1] + x[8] * dt; y[2] = x[2] + x[9] * dt;
+    } else {
+        Quat q = qmul(ldq(x + 3), ldq(u + 3));
+        stq(y + 3, q);
+        y[10] = u[10]; y[11] = u[11]; y[12] = u[12];
+        double rx, ry, rz;
+        qrot(q, u[0], u[1], u[2], rx, ry, rz);
+        y[0] = x[0] + rx; y[1] = x[1] + ry; y[2] = x[2] + rz;
+        y[7] = u[7]; y[8] = u[8]; y[9] = u[9];
+    }
+}
+
+// Eigen toRotationMatrix (through Eigen::Affine3d(orient), UsckfUnitTest.cpp:71), row-wise apply
+__device__ __forceinline__ void qmat_apply(const Quat &q, double cx, double cy, double cz,
+                                           double &ox, double &oy, double &oz)
+{
+    double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    ox = (1 - (tyy + tzz)) * cx + (txy - twz) * cy + (txz + twy) * cz;
+    oy = (txy + twz) * cx + (1 - (txx + tzz)) * cy + (tyz - twx) * cz;
+    oz = (txz - twy) * cx + (tyz + twx) * cy + (1 - (txx + tyy)) * cz;
+}
+
+} // namespace slk

@@ -1,0 +1,279 @@
+"""GPU parity tests: the HIP path (through the C ABI, include/slk.h) against the CPU oracle, the
+committed golden fixtures and closed-form answers.  Tolerance: north_star asks for 1e-6 relative
+on state and covariance; these tests hold the fp64 kernels to TOL = 1e-9 (observed ~1e-13).
+Run with `pytest -m gpu` on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+import scenarios as sc
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def slk():
+    import torch  # noqa: F401  (loads the HIP runtime the library binds to)
+    from slkpkg import slk as mod
+    assert mod.device_count() > 0, "no MI355X visible"
+    return mod
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(1e-300, np.abs(b).max()))
+
+
+def mean_err(lay, a, b):
+    return float(np.abs(o.boxminus(lay, a, b)).max())
+
+
+def test_mfma_f64_fragment_layout(slk):
+    assert slk.load_library().slk_selftest_mfma(0) == 0
+
+
+# ------------------------------------------------------------------ Msckf
+@pytest.mark.parametrize("k", [0, 1, 4, 8])
+def test_msckf_unit_test_scenario_against_golden(slk, k):
+    g = np.load(os.path.join(G, "msckf_unit_test.npz"))
+    t = sc.msckf_unit_test(k)
+    lay = o.layout(o.MULTI, k)
+    f = slk.Msckf(t["mean"], t["P"])
+    u = np.r_[t["dpos"], t["dquat"], t["velocity"], t["angular_velocity"]]
+    for i in range(t["n_predict"]):
+        f.predict(slk.PM_DELTA_POSE, u, t["Q"])
+        assert rel(f.getPk()[0], g[f"k{k}_pred{i}_P"]) <= TOL
+        assert mean_err(lay, f.muState()[0], g[f"k{k}_pred{i}_mean"]) <= TOL
+    z, feat = g[f"k{k}_z"], g[f"k{k}_feat"]
+    f.update(z[None, :], slk.MM_FEATURE_PROJ, feat.reshape(1, -1), 0.01 * np.eye(z.size))
+    assert f.status()[0] == 0
+    assert f.outliers()[0] == int(g[f"k{k}_outliers"][0])
+    assert rel(f.getPk()[0], g[f"k{k}_upd_P"]) <= TOL
+    assert mean_err(lay, f.muState()[0], g[f"k{k}_upd_mean"]) <= TOL
+
+
+def test_msckf_batch_golden_with_outliers(slk):
+    g = np.load(os.path.join(G, "msckf_batch.npz"))
+    s = sc.synthetic_msckf(8, 8)
+    lay = o.layout(o.MULTI, 8)
+    f = slk.Msckf(s["mean"], s["P"])
+    tot = np.zeros(8, dtype=np.int64)
+    for _ in range(3):
+        f.step(slk.PM_DELTA_POSE, s["u"], s["Q"], g["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+        tot += f.outliers()
+    st = f.status()
+    np.testing.assert_array_equal(tot, g["outliers"])
+    assert st[3] == slk.ST_ALL_REJECTED and (np.delete(st, 3) == 0).all()
+    P, M = f.getPk(), f.muState()
+    for b in range(8):
+        assert rel(P[b], g["P"][b]) <= TOL, b
+        assert mean_err(lay, M[b], g["mean"][b]) <= TOL, b
+
+
+@pytest.mark.parametrize("k,m,B", [(0, 2, 96), (1, 2, 96), (3, 6, 64), (8, 8, 64), (12, 8, 16)])
+def test_msckf_step_against_oracle(slk, k, m, B):
+    s = sc.synthetic_msckf(B, k, m=m, seed=100 + k)
+    lay = o.layout(o.MULTI, k)
+    N = s["N"]
+    steps = 3
+    f = slk.Msckf(s["mean"], s["P"])
+    tot = np.zeros(B, dtype=np.int64)
+    for _ in range(steps):
+        f.step(slk.PM_DELTA_POSE, s["u"], s["Q"], s["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+        tot += f.outliers()
+    mean, P = s["mean"].copy(), s["P"].copy()
+    st, out = o.msckf_step_batch(k, m, steps, mean, P, s["u"], s["feat"], s["z"], s["Q"], s["R"])
+    assert st == 0 and (f.status() & ~slk.ST_ALL_REJECTED == 0).all()
+    np.testing.assert_array_equal(tot, out)
+    Pg, Mg = f.getPk(), f.muState()
+    for b in range(B):
+        assert rel(Pg[b], P[b].reshape(N, N).T) <= TOL, b
+        assert mean_err(lay, Mg[b], mean[b]) <= TOL, b
+
+
+def test_separate_predict_update_equals_fused_step(slk):
+    s = sc.synthetic_msckf(16, 4, m=8, seed=7)
+    a = slk.Msckf(s["mean"], s["P"])
+    b = slk.Msckf(s["mean"], s["P"])
+    a.step(slk.PM_DELTA_POSE, s["u"], s["Q"], s["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+    b.predict(slk.PM_DELTA_POSE, s["u"], s["Q"])
+    b.update(s["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+    np.testing.assert_array_equal(a.getPk(), b.getPk())
+    np.testing.assert_array_equal(a.muState(), b.muState())
+
+
+def test_tier_b_host_functor_equals_registered_model(slk):
+    from oracle import np_check as npc
+    s = sc.synthetic_msckf(3, 2, m=4, seed=8)
+    lay = o.layout(o.MULTI, 2)
+    a = slk.Msckf(s["mean"], s["P"])
+    b = slk.Msckf(s["mean"], s["P"])
+    a.predict(slk.PM_DELTA_POSE, s["u"], s["Q"])
+    a.update(s["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+    # the reference's form: opaque callables (boost::bind), here per filter through the sigma-point API
+    X = b.predict_sigma_points()
+    Y = np.array([[npc.pm_delta_pose(x, s["u"][i, 0:3], s["u"][i, 3:7], s["u"][i, 7:10], s["u"][i, 10:13]) for x in X[i]]
+                  for i in range(3)])
+    lib = slk.load_library()
+    Qc = np.ascontiguousarray(s["Q"].T)
+    assert lib.slk_predict_from_sigma(b._h, Y.ctypes.data, Qc.ctypes.data, 0, slk.HOST) == 0
+    X = b.update_sigma_points()
+    Z = np.ascontiguousarray([[npc.mm_feature_proj(x, s["feat"][i]) for x in X[i]] for i in range(3)])
+    Rc = np.ascontiguousarray(s["R"].T)
+    z = np.ascontiguousarray(s["z"])
+    assert lib.slk_update_from_sigma(b._h, Z.ctypes.data, z.ctypes.data, 4, Rc.ctypes.data, 0, 1, slk.HOST) == 0
+    for i in range(3):
+        assert rel(b.getPk()[i], a.getPk()[i]) <= TOL
+        assert mean_err(lay, b.muState()[i], a.muState()[i]) <= TOL
+
+
+def test_linear_kat_closed_form_on_gpu(slk):
+    # G3 on the device: position measurement of clone 1, rotations decoupled => closed-form Kalman update
+    rng = np.random.default_rng(5)
+    k = 2
+    lay = o.layout(o.MULTI, k)
+    N = o.dof(lay)
+    mu = o.set_from_vector(lay, rng.normal(size=N))
+    vec_idx = [i for i in range(N) if not (3 <= i < 6 or (i >= 12 and (i - 12) % 6 >= 3))]
+    rot_idx = [i for i in range(N) if i not in vec_idx]
+
+    def spd(n, scale):
+        A = rng.normal(0, scale, (n, n))
+        return A @ A.T + 0.01 * np.eye(n)
+
+    P = np.zeros((N, N))
+    P[np.ix_(vec_idx, vec_idx)] = spd(len(vec_idx), 0.05)
+    P[np.ix_(rot_idx, rot_idx)] = spd(len(rot_idx), 0.02)
+    R = 0.02 * np.eye(3)
+    H = np.zeros((3, N))
+    H[:, 12:15] = np.eye(3)
+    z = mu[13:16] + np.array([0.05, -0.02, 0.01])
+    f = slk.Msckf(mu, P)
+    f.update(z[None, :], slk.MM_POSE_POSITION, np.array([1.0]), R, gate=0)
+    S = H @ P @ H.T + R
+    K = P @ H.T @ np.linalg.inv(S)
+    assert rel(f.getPk()[0], P - K @ S @ K.T) <= 1e-10
+    assert mean_err(lay, f.muState()[0], o.boxplus(lay, mu, K @ (z - mu[13:16]))) <= 1e-11
+
+
+def test_all_rejected_keeps_predicted_state(slk):
+    s = sc.synthetic_msckf(4, 2, m=4, seed=9)
+    z = s["z"] + 50.0
+    a = slk.Msckf(s["mean"], s["P"])
+    b = slk.Msckf(s["mean"], s["P"])
+    a.step(slk.PM_DELTA_POSE, s["u"], s["Q"], z, slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+    b.predict(slk.PM_DELTA_POSE, s["u"], s["Q"])
+    assert (a.status() == slk.ST_ALL_REJECTED).all() and (a.outliers() == 2).all()
+    np.testing.assert_array_equal(a.getPk(), b.getPk())
+    np.testing.assert_array_equal(a.muState(), b.muState())
+
+
+def test_llt_failure_is_reported_and_state_kept(slk):
+    s = sc.synthetic_msckf(2, 1, m=2, seed=10)
+    P = s["P"].copy()
+    P[1] = -P[1]                                   # filter 1: not positive definite
+    f = slk.Msckf(s["mean"], P)
+    f.update(s["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+    st = f.status()
+    assert st[0] == 0 and st[1] & slk.ST_LLT_FAIL
+    np.testing.assert_array_equal(f.getPk()[1], P[1])
+    np.testing.assert_array_equal(f.muState()[1], s["mean"][1])
+
+
+def test_api_misuse_is_rejected(slk):
+    s = sc.synthetic_msckf(2, 1, m=2, seed=11)
+    f = slk.Msckf(s["mean"], s["P"])
+    lib = slk.load_library()
+    z = np.zeros((2, 3))
+    R = np.eye(3)
+    assert lib.slk_update(f._h, slk.MM_FEATURE_PROJ, None, 0, z.ctypes.data, 3, R.ctypes.data, 0, 1, slk.HOST) == slk.E_INVALID
+    assert lib.slk_update(f._h, 77, None, 0, z.ctypes.data, 2, R.ctypes.data, 0, 1, slk.HOST) == slk.E_INVALID
+    assert lib.slk_predict(f._h, slk.PM_DELTA_POSE, None, 0, None, 0, slk.HOST) == slk.E_INVALID
+    big = slk.Msckf(np.tile(o.identity_state(o.layout(o.MULTI, 20)), (1, 1)), np.eye(132))
+    with pytest.raises(slk.SlkError):
+        big.predict(slk.PM_DELTA_POSE, s["u"][0], s["Q"])      # N = 132 exceeds the LDS-resident kernels
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE cfg3)
+def test_full_size_batch_properties_and_sampled_parity(slk):
+    B, k, m = 4096, 8, 8
+    s = sc.synthetic_msckf(B, k, m=m, seed=0x5EED0000)
+    lay = o.layout(o.MULTI, k)
+    N = s["N"]
+    f = slk.Msckf(s["mean"], s["P"])
+    steps = 2
+    tot = np.zeros(B, dtype=np.int64)
+    for _ in range(steps):
+        f.step(slk.PM_DELTA_POSE, s["u"], s["Q"], s["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+        tot += f.outliers()
+    P, M = f.getPk(), f.muState()
+    st = f.status()
+    assert (st & ~slk.ST_ALL_REJECTED == 0).all()
+    # size-independent properties: exact symmetry of the rebuilt covariance, positive definiteness,
+    # unit quaternions, finite values
+    upd = st == 0
+    assert np.isfinite(P).all() and np.isfinite(M).all()
+    np.testing.assert_array_equal(P[upd], np.transpose(P[upd], (0, 2, 1)))
+    assert np.linalg.eigvalsh(P).min() > 0
+    q = np.concatenate([M[:, 3:7][:, None, :]] + [M[:, 13 + 7 * c + 3:13 + 7 * c + 7][:, None, :] for c in range(k)], axis=1)
+    np.testing.assert_allclose(np.linalg.norm(q, axis=-1), 1.0, atol=1e-12)
+    # sampled parity against the oracle
+    idx = np.r_[0:16, B - 16:B]
+    mean, Pc = s["mean"][idx].copy(), s["P"][idx].copy()
+    stc, out = o.msckf_step_batch(k, m, steps, mean, Pc, np.ascontiguousarray(s["u"][idx]),
+                                  np.ascontiguousarray(s["feat"][idx]), np.ascontiguousarray(s["z"][idx]), s["Q"], s["R"])
+    assert stc == 0
+    np.testing.assert_array_equal(tot[idx], out)
+    for j, b in enumerate(idx):
+        assert rel(P[b], Pc[j].reshape(N, N).T) <= TOL
+        assert mean_err(lay, M[b], mean[j]) <= TOL
+
+
+# ------------------------------------------------------------------ Usckf
+def test_usckf_unit_test_scenario_against_golden(slk):
+    g = np.load(os.path.join(G, "usckf_unit_test.npz"))
+    u = sc.usckf_unit_test()
+    f = slk.Usckf(state_single=u["state_single"], P0_single=u["P0_single"])
+    np.testing.assert_array_equal(f.PkAugmentedState()[0], g["ctor_P"])
+    np.testing.assert_array_equal(f.muState()[0], g["ctor_mean"])
+    for i, (mode, z, R) in enumerate(u["set_measurements"]):
+        f.setMeasurement(mode, z, R)
+        np.testing.assert_array_equal(f.PkAugmentedState()[0], g[f"setm{i}_P"])
+        np.testing.assert_array_equal(f.muState()[0], g[f"setm{i}_mean"])
+    assert f.N == 48
+    lay = o.layout(o.AUGMENTED, 0, 3, 9)
+    uu = np.r_[u["velocity"], u["angular_velocity"], u["dt"]]
+    for i in range(u["n_predict"]):
+        f.predict(slk.PM_CONST_VELOCITY, uu, u["Q"])
+        assert f.status()[0] == 0
+        assert rel(f.PkAugmentedState()[0], g[f"pred{i}_P"]) <= TOL
+        assert mean_err(lay, f.muState()[0], g[f"pred{i}_mean"]) <= TOL
+    # literal update(): indefinite 48x48 covariance -> reported, state kept
+    before_P, before_m = f.PkAugmentedState(), f.muState()
+    f.update(u["z"][None, :], slk.MM_VO_RELATIVE, None, u["R"])
+    assert f.status()[0] & slk.ST_LLT_FAIL
+    np.testing.assert_array_equal(f.PkAugmentedState(), before_P)
+    np.testing.assert_array_equal(f.muState(), before_m)
+
+
+def test_usckf_spd_predict_update_against_golden_and_oracle(slk):
+    g = np.load(os.path.join(G, "usckf_spd.npz"))
+    s = sc.synthetic_usckf(4)
+    lay = o.layout(o.AUGMENTED, 0, 3, 9)
+    f = slk.Usckf(mean=s["mean"], P=s["P"], nfk=3, nfkl=9)
+    h = slk.Usckf(mean=s["mean"], P=s["P"], nfk=3, nfkl=9)
+    for _ in range(2):
+        f.predict(slk.PM_CONST_VELOCITY, s["u"], s["Q"])
+        f.update(s["z"], slk.MM_VO_RELATIVE, None, s["R"])
+        h.step(slk.PM_CONST_VELOCITY, s["u"], s["Q"], s["z"], slk.MM_VO_RELATIVE, None, s["R"])
+    assert (f.status() == 0).all()
+    P, M = f.PkAugmentedState(), f.muState()
+    for b in range(4):
+        assert rel(P[b], g["P"][b]) <= TOL
+        assert mean_err(lay, M[b], g["mean"][b]) <= TOL
+    np.testing.assert_array_equal(h.PkAugmentedState(), P)
+    np.testing.assert_array_equal(h.muState(), M)
