@@ -17,15 +17,20 @@ def hipcc():
     return "hipcc"
 
 
-def build(force=False, verbose=False):
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in DEPS):
-        return OUT
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT, SRC]
+def build(force=False, verbose=False, stamps=False):
+    """stamps=True builds the DIAGNOSTIC variant libslk_hip_stamps.so (in-kernel phase stamps; never
+    the product: its run time is not quotable)."""
+    out = OUT.replace(".so", "_stamps.so") if stamps else OUT
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in DEPS):
+        return out
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", out, SRC]
+    if stamps:
+        cmd.insert(1, "-DSLK_STAMPS")
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, stamps="--stamps" in sys.argv))

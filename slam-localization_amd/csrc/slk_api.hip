@@ -180,7 +180,7 @@ int slk_get_state(slk_filter *f, double *mean, double *P, int where)
 template <int NT, int NTHREADS>
 static int launch_msckf_inst(slk_filter *f, const KArgs &a)
 {
-    Carve cv = carve_step(a.lay.N, a.lay.Nq, a.m, a.lay.nso3, NT);
+    Carve cv = carve_step(a.lay, a.m, NT);
     size_t lds = (size_t)cv.total * sizeof(double);
     if (lds > 160 * 1024) { g_err = "state too large for the LDS-resident kernel"; return SLK_E_UNSUPPORTED; }
     auto kern = msckf_step_kernel<NT, NTHREADS>;
@@ -208,12 +208,13 @@ static int launch_msckf(slk_filter *f, const KArgs &a)
     }
 }
 
-static int launch_usckf(slk_filter *f, const KArgs &a)
+template <int NT>
+static int launch_usckf_inst(slk_filter *f, const KArgs &a)
 {
-    UCarve cv = carve_usckf(a.lay.N, a.lay.Nq, a.m);
+    UCarve cv = carve_usckf(a.lay.N, a.lay.Nq, a.m, NT);
     size_t lds = (size_t)cv.total * sizeof(double);
     if (lds > 160 * 1024) { g_err = "state too large for the LDS-resident kernel"; return SLK_E_UNSUPPORTED; }
-    auto kern = usckf_kernel<256>;
+    auto kern = usckf_kernel<NT, 256>;
     static size_t configured = 0;
     if (lds > configured) {
         HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -224,9 +225,29 @@ static int launch_usckf(slk_filter *f, const KArgs &a)
     return SLK_OK;
 }
 
+static int launch_usckf(slk_filter *f, const KArgs &a)
+{
+    int NT = (a.lay.N + 15) / 16;
+    switch (NT) {
+    case 3: return launch_usckf_inst<3>(f, a);
+    case 4: return launch_usckf_inst<4>(f, a);
+    case 5: return launch_usckf_inst<5>(f, a);
+    case 6: return launch_usckf_inst<6>(f, a);
+    default: g_err = "Usckf state dimension above 96 is not supported by this build"; return SLK_E_UNSUPPORTED;
+    }
+}
+
+#ifdef SLK_STAMPS
+static long long *g_dbg = nullptr;
+extern "C" void slk_debug_set_stamps(long long *device_buffer) { g_dbg = device_buffer; }   // [B][32], diagnostic build only
+#endif
+
 static void base_args(slk_filter *f, KArgs &a)
 {
     memset(&a, 0, sizeof(a));
+#ifdef SLK_STAMPS
+    a.dbg = g_dbg;
+#endif
     a.B = f->B;
     a.lay = f->lay;
     a.mean = f->d_mean; a.P = f->d_P; a.status = f->d_status; a.outliers = f->d_outliers;
@@ -524,7 +545,7 @@ int slk_selftest_mfma(int device)
     hipLaunchKernelGGL(selftest_mfma_kernel, dim3(1), dim3(64), 0, 0, dA, dB, dC);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpy(hC, dC, sizeof(hC), hipMemcpyDeviceToHost));
-    (void)hipFree(dA); hipFree(dB); hipFree(dC);
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
     int bad = 0;
     for (int r = 0; r < 16; ++r)
         for (int c = 0; c < 16; ++c) {

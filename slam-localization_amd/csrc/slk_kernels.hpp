@@ -14,9 +14,9 @@ namespace slk {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int KP = 32;       // sigma points per rebuild panel (8 MFMA k-steps)
+constexpr int KP = 16;       // sigma points per rebuild panel (4 MFMA k-steps), double-buffered
 constexpr int MAXM = 32;     // max measurement rows handled on chip
-constexpr int PRED_SCRATCH = 1280;  // doubles of pool used by the 12-DOF predict phase
+constexpr int PRED_SCRATCH = 1536;  // doubles of pool used by the 12-DOF predict phase
 
 struct Lay { int kind, k, nfk, nfkl, N, Nq, nso3; };
 
@@ -31,7 +31,16 @@ struct KArgs {
     const double *R; int r_stride; int gate; const double *Zext;
     // tier B sigma-point emission: 1 = predict sigma points, 2 = update sigma points
     int emit; double *Xout;
+    long long *dbg;   // phase stamps, diagnostic builds (-DSLK_STAMPS) only; always null in the product
 };
+
+#ifdef SLK_STAMPS
+#define SLK_STAMP(i) do { if (tid == 0 && a.dbg) a.dbg[(size_t)bidx * 32 + (i)] = clock64(); } while (0)
+#define SLK_NOTE(i, v) do { if (tid == 0 && a.dbg) a.dbg[(size_t)bidx * 32 + (i)] = (long long)(v); } while (0)
+#else
+#define SLK_STAMP(i) do { } while (0)
+#define SLK_NOTE(i, v) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------ layout helpers
 // State.hpp:141-149, :246-252, :384-396 (MultiState tangent order), :567-588 (AugmentedState)
@@ -75,17 +84,31 @@ __host__ __device__ __forceinline__ void pose_of(const Lay &L, int c, int &tp, i
 }
 
 // ------------------------------------------------------------------ LDS carve (in doubles)
-struct Carve { int A, pdiag, mu, ref, delta, md, small, pool, total; int lda, S, SP, LDD; };
+struct Carve {
+    int A, pdiag, mu, ref, delta, md, small, colbuf, pool, total;
+    int lda, S, LDD, TN, W;   // W = stored rotation-row items (sum over blocks of 2*(toff+3)+1)
+};
 
 __host__ __device__ inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
 
-__host__ __device__ inline Carve carve_step(int N, int Nq, int m, int nso3, int NT)
+// number of sigma points whose SO(3) block b differs from X_0's: columns j <= toff_b + 2 of the
+// lower-triangular factor, two signs, plus i = 0
+__host__ __device__ __forceinline__ int rot_count(const Lay &L, int b)
 {
+    int c = 2 * (so3_toff(L, b) + 3) + 1, S = 2 * L.N + 1;
+    return c < S ? c : S;
+}
+
+__host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT)
+{
+    const int N = L.N, Nq = L.Nq;
     Carve c;
     c.lda = N | 1;
     c.S = 2 * N + 1;
-    c.SP = c.S;                                  // odd row stride of the rotation-row store
+    c.TN = 16 * NT;
     c.LDD = 16 * NT + ((NT & 1) ? 0 : 16);       // LDD % 32 == 16: the two 16-lane halves of a b64 read hit disjoint banks
+    c.W = 0;
+    for (int b = 0; b < L.nso3; ++b) c.W += rot_count(L, b);
     int o = 0;
     c.A = o;      o += round_up(N * c.lda, 2);
     c.pdiag = o;  o += round_up(N, 2);
@@ -93,10 +116,14 @@ __host__ __device__ inline Carve carve_step(int N, int Nq, int m, int nso3, int 
     c.ref = o;    o += round_up(Nq, 2);
     c.delta = o;  o += round_up(N, 2);
     c.md = o;     o += round_up(N, 2);
-    c.small = o;  o += 64;
+    c.small = o;  o += 96;
+    c.colbuf = o; o += 2 * (c.TN > 32 ? c.TN : 32);
     c.pool = o;
-    int upd1 = round_up(c.S * m, 2) + 3 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (2 * m + 1), 2) + 4 * round_up(m, 2);
-    int upd2 = round_up(3 * nso3 * c.SP, 2) + KP * c.LDD;
+    // measurement part: Z[S*m] DZ[N*m] Pxz[N*m] K[N*m] Sm[m*m] G[m*(2m+1)] zbar innov
+    int upd1 = round_up(c.S * m, 2) + 3 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (2 * m + 1), 2)
+               + 4 * round_up(m, 2);
+    // applyDelta part: DR[3*W] + double-buffered panel
+    int upd2 = round_up(3 * c.W, 2) + 2 * KP * c.LDD;
     int pool = PRED_SCRATCH;
     if (upd1 > pool) pool = upd1;
     if (upd2 > pool) pool = upd2;
@@ -133,29 +160,103 @@ __device__ __forceinline__ Quat sigma_quat(const Lay &L, const double *mu, const
                 so3_exp(pert(A, lda, delta, to, s), pert(A, lda, delta, to + 1, s), pert(A, lda, delta, to + 2, s)));
 }
 
-// ------------------------------------------------------------------ in-place lower Cholesky in LDS
-// Right-looking; only the lower triangle is read or written (the strict upper triangle keeps
-// whatever the caller stored there).  Returns -1, or the first non-positive pivot (same value in
-// every thread).  Eigen::LLT in the reference never has its info() read (Msckf.hpp:412-413).
-template <int NTHREADS>
-__device__ int chol_lower_inplace(double *A, int n, int lda, int tid)
-{
-    constexpr int NW = NTHREADS / 64;
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int k = 0; k < n; ++k) {
-        double d = A[k + k * lda];
-        if (!(d > 0.0)) return k;
-        double s = sqrt(d);
-        for (int i = k + 1 + tid; i < n; i += NTHREADS) A[i + k * lda] = A[i + k * lda] / s;
-        __syncthreads();
-        for (int j = k + 1 + wave; j < n; j += NW) {
-            double ljk = A[j + k * lda];
-            for (int i = j + lane; i < n; i += 64) A[i + j * lda] -= A[i + k * lda] * ljk;
+
+// ------------------------------------------------------------------ register-resident Cholesky
+// Lower Cholesky of an n x n matrix with the trailing matrix held in REGISTERS, block-cyclic over a
+// GD x GD thread grid (thread (ti,tj) owns elements i = ti + GD*sa, j = tj + GD*sb).  Per column: the
+// owners publish the raw column through a double-buffered LDS vector, ONE barrier, everybody applies
+// a_ij -= c_i c_j / d.  The finished factor is written to the lower triangle of A (the strict upper
+// triangle of A is never touched).  init(i, j) supplies the initial lower-triangle element, so the
+// covariance downdate is fused into the load.  Returns -1 or the first non-positive pivot (uniform).
+// Eigen::LLT in the reference never has its info() read (Msckf.hpp:412-413, Usckf.hpp:537-538).
+template <int NTHREADS> struct Grid { static constexpr int GD = (NTHREADS >= 256) ? 16 : 8; };
+
+// one GD-wide block of columns, KB = compile-time slot index of the pivot columns
+template <int NTHREADS, int SD, int KB>
+struct CholCols {
+    __device__ __forceinline__ static void run(double (&a)[SD][SD], double *A, int n, int lda, double *colbuf,
+                                               int ti, int tj, bool active, int &fail)
+    {
+        if constexpr (KB < SD) {
+            constexpr int GD = Grid<NTHREADS>::GD;
+            constexpr int CB = SD * GD;
+            if (fail < 0) {
+                for (int kt = 0; kt < GD; ++kt) {
+                    const int k = KB * GD + kt;
+                    if (k >= n) break;
+                    double *buf = colbuf + (k & 1) * CB;
+                    if (active && tj == kt) {
+#pragma unroll
+                        for (int sa = 0; sa < SD; ++sa) {
+                            int i = ti + GD * sa;
+                            if (i >= k && i < n) buf[i] = a[sa][KB];
+                        }
+                    }
+                    __syncthreads();
+                    const double d = buf[k];
+                    if (!(d > 0.0)) { fail = k; break; }
+                    const double sq = sqrt(d), inv = 1.0 / d;
+                    if (active && tj == kt) {
+#pragma unroll
+                        for (int sa = 0; sa < SD; ++sa) {
+                            int i = ti + GD * sa;
+                            if (i > k && i < n) A[i + k * lda] = a[sa][KB] / sq;
+                            else if (i == k) A[k + k * lda] = sq;
+                        }
+                    }
+                    double ci[SD], cj[SD];
+#pragma unroll
+                    for (int sa = 0; sa < SD; ++sa) {
+                        int i = ti + GD * sa;
+                        ci[sa] = (i > k && i < n) ? buf[i] : 0.0;
+                    }
+#pragma unroll
+                    for (int sb = KB; sb < SD; ++sb) {
+                        int j = tj + GD * sb;
+                        cj[sb] = (j > k && j < n) ? buf[j] * inv : 0.0;
+                    }
+#pragma unroll
+                    for (int sa = 0; sa < SD; ++sa)
+#pragma unroll
+                        for (int sb = KB; sb < SD; ++sb) a[sa][sb] -= ci[sa] * cj[sb];
+                }
+            }
+            CholCols<NTHREADS, SD, KB + 1>::run(a, A, n, lda, colbuf, ti, tj, active, fail);
         }
-        if (tid == 0) A[k + k * lda] = s;
-        __syncthreads();
     }
-    return -1;
+};
+
+template <int NTHREADS, int SD, class InitFn>
+__device__ __forceinline__ int chol_lower_regs(double *A, int n, int lda, double *colbuf, int tid, InitFn init)
+{
+    constexpr int GD = Grid<NTHREADS>::GD;
+    const int ti = tid % GD, tj = tid / GD;
+    const bool active = tid < GD * GD;
+    double a[SD][SD];
+#pragma unroll
+    for (int sa = 0; sa < SD; ++sa)
+#pragma unroll
+        for (int sb = 0; sb < SD; ++sb) {
+            int i = ti + GD * sa, j = tj + GD * sb;
+            a[sa][sb] = (active && i < n && j <= i) ? init(i, j) : 0.0;
+        }
+    int fail = -1;
+    CholCols<NTHREADS, SD, 0>::run(a, A, n, lda, colbuf, ti, tj, active, fail);
+    __syncthreads();
+    return fail;
+}
+
+// ------------------------------------------------------------------ small reductions
+// sum over i in [0, cnt) of term(i), spread over G consecutive lanes (G = 2^k <= 64); every lane of
+// the group gets the total
+template <int G, class TermFn>
+__device__ __forceinline__ double group_sum(int sub, int cnt, TermFn term)
+{
+    double s = 0.0;
+    for (int i = sub; i < cnt; i += G) s += term(i);
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    return s;
 }
 
 // ------------------------------------------------------------------ registered measurement models
@@ -204,18 +305,98 @@ __host__ __device__ __forceinline__ int measure_features(int mm, int m)
     return mm == SLK_MM_FEATURE_PROJ ? m / 2 : (mm == SLK_MM_POSE_POSITION ? 1 : m / 3);
 }
 
+
+// ------------------------------------------------------------------ measurement moments
+// Z = h(X) over the implicit sigma points of (mu, L), mean_z, innovation, S = 1/2 dZ dZ^T + R and
+// covXZ = 1/2 sum (X_i [-] mu)(Z_i - mean_z)^T  (Msckf.hpp:231-239, Usckf.hpp:277-283).
+// Lf holds the Cholesky factor in its lower triangle (ld lda).  *flag must be 0 on entry.
+template <int NTHREADS>
+__device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L, int bidx, int tid, const double *mu,
+                                                    const double *A, int lda, double *Z, double *DZ, double *Pxz,
+                                                    double *Sm, double *zbar, double *innov, int *flag)
+{
+    const int N = L.N, m = a.m, S = 2 * N + 1, nso3 = L.nso3;
+    const double *mp = a.mp ? a.mp + (size_t)bidx * a.mp_stride : nullptr;
+    // Z = h(X): Msckf.hpp:231-232
+    if (a.mm == SLK_MODEL_EXTERNAL) {
+        const double *Ze = a.Zext + (size_t)bidx * S * m;
+        for (int e = tid; e < S * m; e += NTHREADS) Z[e] = Ze[e];
+    } else {
+        int nf = measure_features(a.mm, m);
+        for (int e = tid; e < S * nf; e += NTHREADS) {
+            int f = e % nf, i = e / nf;
+            measure_item(a, L, mp, mu, A, lda, i, f, Z + i * m);
+        }
+    }
+    // rotation columns of L longer than pi make log(exp(v)) wrap (MTK log uses atan): flag them
+    for (int e = tid; e < N * nso3; e += NTHREADS) {
+        int j = e % N, b = e / N, t0 = so3_toff(L, b);
+        double v0 = Lz(A, lda, t0, j), v1 = Lz(A, lda, t0 + 1, j), v2 = Lz(A, lda, t0 + 2, j);
+        if (v0 * v0 + v1 * v1 + v2 * v2 >= 9.869604401089358) *flag = 1;
+    }
+    __syncthreads();
+    SLK_STAMP(4);
+    // mean_z (:234), innovation (:236); DZ
+    for (int r = tid / 32; r < m; r += NTHREADS / 32) {
+        double sum = group_sum<32>(tid & 31, S, [&](int i) { return Z[i * m + r]; });
+        if ((tid & 31) == 0) {
+            double zb = sum / (double)S;
+            zbar[r] = zb;
+            innov[r] = a.z[(size_t)bidx * m + r] - zb;
+        }
+    }
+    for (int e = tid; e < N * m; e += NTHREADS) {
+        int r = e % m, j = e / m;
+        DZ[e] = Z[(2 * j + 1) * m + r] - Z[(2 * j + 2) * m + r];
+    }
+    __syncthreads();
+    SLK_STAMP(5);
+    // S = cov(Z) + R (:238), covXZ (:239 -> :635-657).  X_i [-] mu = +-L.col(j) (and 0 for X_0):
+    // covXZ = 1/2 L * (Z_{2j+1} - Z_{2j+2})_j ; exact while every rotation column is shorter than pi.
+    const double *R = a.R + (size_t)bidx * a.r_stride;
+    for (int e = tid / 4; e < m * m; e += NTHREADS / 4) {
+        int r = e % m, c = e / m;
+        double zr = zbar[r], zc = zbar[c];
+        double sum = group_sum<4>(tid & 3, S, [&](int i) { return (Z[i * m + r] - zr) * (Z[i * m + c] - zc); });
+        if ((tid & 3) == 0) Sm[e] = 0.5 * sum + R[e];
+    }
+    const bool wrap = *flag != 0;
+    for (int e = tid; e < N * m; e += NTHREADS) {
+        int t = e % N, r = e / N;
+        double sum = 0.0;
+        if (!wrap) {
+            for (int j = 0; j <= t; ++j) sum += A[t + j * lda] * DZ[j * m + r];
+        } else {
+            int blk = -1, comp = 0, s = t2s(L, t, blk, comp), t0 = t - comp;
+            for (int j = 0; j <= t; ++j) {
+                double w = 1.0;
+                if (s < 0) {
+                    double v0 = Lz(A, lda, t0, j), v1 = Lz(A, lda, t0 + 1, j), v2 = Lz(A, lda, t0 + 2, j);
+                    double th = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
+                    if (th >= 3.141592653589793) w = 2.0 * atan(tan(0.5 * th)) / th;
+                }
+                sum += w * A[t + j * lda] * DZ[j * m + r];
+            }
+        }
+        Pxz[e] = 0.5 * sum;
+    }
+    __syncthreads();
+}
+
+
 // ------------------------------------------------------------------ 12-DOF predict phase
 // Msckf.hpp:102-165 == Usckf.hpp:117-181: sigma points of the current State, process model map,
 // manifold mean, new Pk_i = cov + Q.  Pblk = 12x12 (ld 13) lower block of the covariance on entry,
 // Cholesky factor on exit (Usckf needs it for Fk); x13 = current State mean, replaced by the new
-// mean.  Pn (12x12, ld 12) receives the new block.  Returns 0 or status bits (uniform).
-// scratch layout (doubles): Ys[25*13] dbuf[25*12] refs[16] mdel[16]
+// mean.  Pn (12x12, ld 12) receives the new block.  Returns 0 or status bits (uniform), -1 after a
+// sigma-point emission.  scratch (doubles): Ys[25*13] dbuf[25*12] refs[16] mdel[16] colbuf[64]
 template <int NTHREADS, bool WANT_PXY>
-__device__ int predict_phase(const KArgs &a, int bidx, int tid, double *Pblk, double *x13, double *Pn,
+__device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, double *Pblk, double *x13, double *Pn,
                              double *scr, double *Pxy /* 12x12 ld 12, only if WANT_PXY */)
 {
-    double *Ys = scr, *dbuf = scr + 25 * 13, *refs = dbuf + 25 * 12, *mdel = refs + 16;
-    int fail = chol_lower_inplace<NTHREADS>(Pblk, 12, 13, tid);
+    double *Ys = scr, *dbuf = scr + 25 * 13, *refs = dbuf + 25 * 12, *mdel = refs + 16, *cb = mdel + 16;
+    constexpr int SD12 = (12 + Grid<NTHREADS>::GD - 1) / Grid<NTHREADS>::GD;
+    int fail = chol_lower_regs<NTHREADS, SD12>(Pblk, 12, 13, cb, tid, [&](int i, int j) { return Pblk[i + j * 13]; });
     if (fail >= 0) return SLK_ST_LLT_FAIL;
     const double *u = a.u ? a.u + (size_t)bidx * a.u_stride : nullptr;
     if (tid < 25) {
@@ -336,32 +517,41 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NTHREADS / 64;
+    constexpr int GD = Grid<NTHREADS>::GD;
+    constexpr int SDN = (16 * NT + GD - 1) / GD;          // Cholesky register slots per dimension
+    constexpr int SDM = (MAXM + GD - 1) / GD;
     const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Lay L = a.lay;
     const int N = L.N, Nq = L.Nq, m = a.m, nso3 = L.nso3;
-    const Carve cv = carve_step(N, Nq, m, nso3, NT);
-    const int lda = cv.lda, S = cv.S, SP = cv.SP, LDD = cv.LDD;
+    const Carve cv = carve_step(L, m, NT);
+    const int lda = cv.lda, S = cv.S, LDD = cv.LDD;
     double *A = smem + cv.A, *pdiag = smem + cv.pdiag, *mu = smem + cv.mu, *ref = smem + cv.ref;
-    double *delta = smem + cv.delta, *md = smem + cv.md, *pool = smem + cv.pool;
-    int *ish = reinterpret_cast<int *>(smem + cv.small);      // [0..MAXM) idx, [40] count, [41] outliers, [42] flag
+    double *delta = smem + cv.delta, *md = smem + cv.md, *colbuf = smem + cv.colbuf, *pool = smem + cv.pool;
+    int *ish = reinterpret_cast<int *>(smem + cv.small);      // [0..MAXM) idx, [40] count, [41] outliers, [42] flag, [48..) rot offsets
+    int *roff = ish + 48;                                     // nso3 + 1 prefix offsets of the stored rotation items
     double *gmean = a.mean + (size_t)bidx * Nq;
     double *gP = a.P + (size_t)bidx * N * N;
     int status = 0;
     if (a.do_update && tid == 0) a.outliers[bidx] = 0u;
+    SLK_STAMP(0);
 
     // ---- load: mean, and the LOWER triangle of P mirrored into both triangles (only the lower
     // triangle of Pk is ever read by Msckf::predict/update: LLT at :412, :447; the rebuild overwrites all)
     for (int e = tid; e < Nq; e += NTHREADS) mu[e] = gmean[e];
+    if (tid == 0) {
+        int o = 0;
+        for (int b = 0; b < nso3; ++b) { roff[b] = o; o += rot_count(L, b); }
+        roff[nso3] = o;
+        ish[42] = 0;
+    }
     if (a.do_update || a.emit == 2) {
-        for (int e = tid; e < N * N; e += NTHREADS) {
-            int r = e % N, c = e / N;
-            if (r >= c) {
-                double v = gP[e];
+        for (int c = wave; c < N; c += NW)
+            for (int r = c + lane; r < N; r += 64) {
+                double v = gP[r + (size_t)c * N];
                 A[r + c * lda] = v;
                 A[c + r * lda] = v;
                 if (r == c) pdiag[r] = v;
             }
-        }
     } else {
         for (int e = tid; e < 144; e += NTHREADS) {
             int r = e % 12, c = e / 12;
@@ -369,18 +559,17 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
         }
     }
     __syncthreads();
+    SLK_STAMP(1);
 
     // ---- predict: Msckf.hpp:89-189 (state<->clone cross-covariances stay stale: :171-182)
     if (a.do_predict || a.emit == 1) {
-        double *Pblk = pool, *Pn = pool + 160, *scr = pool + 320;   // 156 + 144 + (325+300+32)
+        double *Pblk = pool, *Pn = pool + 160, *scr = pool + 320;   // 156 + 144 + (325+300+32+64)
         for (int e = tid; e < 144; e += NTHREADS) { int r = e % 12, c = e / 12; Pblk[r + c * 13] = A[r + c * lda]; }
         __syncthreads();
         int st = predict_phase<NTHREADS, false>(a, bidx, tid, Pblk, mu, Pn, scr, nullptr);
         if (a.emit == 1) return;
-        if (st & SLK_ST_LLT_FAIL) {
-            status |= st;                       // predict skipped, filter unchanged
-        } else {
-            status |= st;
+        status |= st;
+        if (!(st & SLK_ST_LLT_FAIL)) {                // else: predict skipped, filter unchanged
             for (int e = tid; e < 144; e += NTHREADS) {
                 int r = e % 12, c = e / 12;
                 gP[r + (size_t)c * N] = Pn[e];
@@ -393,9 +582,11 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
         __syncthreads();
     }
 
+    SLK_STAMP(2);
     if (a.do_update || a.emit == 2) {
         // ---- sigma points of the full state: Msckf.hpp:228-229 -> :400-431
-        int fail = chol_lower_inplace<NTHREADS>(A, N, lda, tid);
+        int fail = chol_lower_regs<NTHREADS, SDN>(A, N, lda, colbuf, tid, [&](int i, int j) { return A[i + j * lda]; });
+        SLK_STAMP(3);
         if (fail >= 0) {
             status |= SLK_ST_LLT_FAIL;
         } else if (a.emit == 2) {
@@ -414,65 +605,16 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
         } else {
             // ---- pool carve for the measurement part
             double *Z = pool;                                   // [S][m]
-            double *Pxz = Z + round_up(S * m, 2);               // N x m (ld N)
-            double *K = Pxz + round_up(N * m, 2);
-            double *KS = K + round_up(N * m, 2);
-            double *Sm = KS + round_up(N * m, 2);               // m x m (ld m)
-            double *G = Sm + round_up(m * m, 2);                // m x (2m+1) row-major Gauss-Jordan tableau
+            double *DZ = Z + round_up(S * m, 2);                // [N][m]: Z_{2j+1} - Z_{2j+2}
+            double *Pxz = DZ + round_up(N * m, 2);              // N x m (ld N)
+            double *K = Pxz + round_up(N * m, 2);               // N x m' (ld N)
+            double *Sm = K + round_up(N * m, 2);                // m x m (ld m)
+            double *G = Sm + round_up(m * m, 2);                // m' x m' factor of S (ld m'+1) / Gauss-Jordan tableau
             double *zbar = G + round_up(m * (2 * m + 1), 2);
             double *innov = zbar + round_up(m, 2);
             int *idx = ish;
-            const double *mp = a.mp ? a.mp + (size_t)bidx * a.mp_stride : nullptr;
-
-            // Z = h(X): Msckf.hpp:231-232
-            if (a.mm == SLK_MODEL_EXTERNAL) {
-                const double *Ze = a.Zext + (size_t)bidx * S * m;
-                for (int e = tid; e < S * m; e += NTHREADS) Z[e] = Ze[e];
-            } else {
-                int nf = measure_features(a.mm, m);
-                for (int e = tid; e < S * nf; e += NTHREADS) {
-                    int f = e % nf, i = e / nf;
-                    measure_item(a, L, mp, mu, A, lda, i, f, Z + i * m);
-                }
-            }
-            __syncthreads();
-            // mean_z (:234, accumulate then divide), innovation (:236)
-            for (int r = tid; r < m; r += NTHREADS) {
-                double sum = 0.0;
-                for (int i = 0; i < S; ++i) sum += Z[i * m + r];
-                double zb = sum / (double)S;
-                zbar[r] = zb;
-                innov[r] = a.z[(size_t)bidx * m + r] - zb;
-            }
-            __syncthreads();
-            // S = cov(Z) + R (:238), covXZ (:239 -> :635-657).  X_i [-] mu = +-L.col(j) (and 0 for X_0):
-            // covXZ = 1/2 L * (Z_{2j+1} - Z_{2j+2})_j ; exact while every rotation column is shorter than pi.
-            const double *R = a.R + (size_t)bidx * a.r_stride;
-            for (int e = tid; e < m * m; e += NTHREADS) {
-                int r = e % m, c = e / m;
-                double zr = zbar[r], zc = zbar[c], sum = 0.0;
-                for (int i = 0; i < S; ++i) sum += (Z[i * m + r] - zr) * (Z[i * m + c] - zc);
-                Sm[e] = 0.5 * sum + R[e];
-            }
-            for (int e = tid; e < N * m; e += NTHREADS) {
-                int t = e % N, r = e / N, blk = -1, comp = 0;
-                int s = t2s(L, t, blk, comp);
-                double sum = 0.0;
-                if (s >= 0) {
-                    for (int j = 0; j <= t; ++j) sum += A[t + j * lda] * (Z[(2 * j + 1) * m + r] - Z[(2 * j + 2) * m + r]);
-                } else {
-                    // rotation rows: log(exp(v)) wraps once |v| >= pi (MTK log uses atan): scale the column
-                    int t0 = t - comp;
-                    for (int j = 0; j <= t; ++j) {
-                        double v0 = Lz(A, lda, t0, j), v1 = Lz(A, lda, t0 + 1, j), v2 = Lz(A, lda, t0 + 2, j);
-                        double th = sqrt(v0 * v0 + v1 * v1 + v2 * v2), w = 1.0;
-                        if (th >= 3.141592653589793) w = 2.0 * atan(tan(0.5 * th)) / th;
-                        sum += w * A[t + j * lda] * (Z[(2 * j + 1) * m + r] - Z[(2 * j + 2) * m + r]);
-                    }
-                }
-                Pxz[e] = 0.5 * sum;
-            }
-            __syncthreads();
+            measurement_moments<NTHREADS>(a, L, bidx, tid, mu, A, lda, Z, DZ, Pxz, Sm, zbar, innov, &ish[42]);
+            SLK_STAMP(6);
             // removeOutliers (:241 -> :723-754) incl. the shifted second erase (:741-744)
             if (tid == 0) {
                 int cnt = m;
@@ -498,88 +640,106 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
                 }
                 ish[40] = cnt;
                 ish[41] = (int)nout;
-                ish[42] = 0;
             }
             __syncthreads();
+            SLK_STAMP(7);
             const int mmr = ish[40];
             if (tid == 0) a.outliers[bidx] = (unsigned)ish[41];
             if (mmr == 0) {
                 status |= SLK_ST_ALL_REJECTED;                         // :250, nothing applied
             } else {
-                // S^-1 by Gauss-Jordan with partial pivoting (reference: Eigen PartialPivLU inverse, :257)
-                const int ldg = 2 * mmr + 1;
-                for (int e = tid; e < mmr * mmr; e += NTHREADS) {
-                    int r = e % mmr, c = e / mmr;
-                    G[r * ldg + c] = Sm[idx[r] + m * idx[c]];
-                    G[r * ldg + mmr + c] = (r == c) ? 1.0 : 0.0;
+                // K = covXZ * S^-1 (:257).  S = 1/2 dZ dZ^T + R is symmetric positive definite for any
+                // valid R: factor it (S = Ls Ls^T) and solve row-wise; a non-SPD S falls back to
+                // Gauss-Jordan with partial pivoting (the reference inverts with PartialPivLU).
+                const int ldg = mmr + 1;
+                int sfail = chol_lower_regs<NTHREADS, SDM>(G, mmr, ldg, colbuf, tid,
+                                                           [&](int i, int j) { return Sm[idx[i] + m * idx[j]]; });
+                bool singular = false;
+                if (sfail < 0) {
+                    for (int t = tid; t < N; t += NTHREADS) {
+                        for (int c = 0; c < mmr; ++c) {               // forward: Ls w = p
+                            double sum = Pxz[t + N * idx[c]];
+                            for (int p = 0; p < c; ++p) sum -= G[c + p * ldg] * K[t + N * p];
+                            K[t + N * c] = sum / G[c + c * ldg];
+                        }
+                        for (int c = mmr - 1; c >= 0; --c) {          // backward: Ls^T x = w
+                            double sum = K[t + N * c];
+                            for (int p = c + 1; p < mmr; ++p) sum -= G[p + c * ldg] * K[t + N * p];
+                            K[t + N * c] = sum / G[c + c * ldg];
+                        }
+                    }
+                } else {
+                    const int ldj = 2 * mmr + 1;
+                    __syncthreads();
+                    for (int e = tid; e < mmr * mmr; e += NTHREADS) {
+                        int r = e % mmr, c = e / mmr;
+                        G[r * ldj + c] = Sm[idx[r] + m * idx[c]];
+                        G[r * ldj + mmr + c] = (r == c) ? 1.0 : 0.0;
+                    }
+                    __syncthreads();
+                    for (int k = 0; k < mmr; ++k) {
+                        int piv = k;
+                        double best = fabs(G[k * ldj + k]);
+                        for (int i = k + 1; i < mmr; ++i) {
+                            double v = fabs(G[i * ldj + k]);
+                            if (v > best) { best = v; piv = i; }
+                        }
+                        if (!(best > 0.0)) { singular = true; break; }
+                        __syncthreads();
+                        if (piv != k)
+                            for (int c = tid; c < 2 * mmr; c += NTHREADS) {
+                                double t0 = G[k * ldj + c]; G[k * ldj + c] = G[piv * ldj + c]; G[piv * ldj + c] = t0;
+                            }
+                        __syncthreads();
+                        double pv = G[k * ldj + k];
+                        __syncthreads();
+                        for (int c = tid; c < 2 * mmr; c += NTHREADS) G[k * ldj + c] = G[k * ldj + c] / pv;
+                        __syncthreads();
+                        for (int r = tid; r < mmr; r += NTHREADS) {
+                            if (r == k) continue;
+                            double f = G[r * ldj + k];
+                            for (int c = 0; c < 2 * mmr; ++c) G[r * ldj + c] -= f * G[k * ldj + c];
+                        }
+                        __syncthreads();
+                    }
+                    if (!singular)
+                        for (int e = tid; e < N * mmr; e += NTHREADS) {
+                            int t = e % N, c = e / N;
+                            double sum = 0.0;
+                            for (int c2 = 0; c2 < mmr; ++c2) sum += Pxz[t + N * idx[c2]] * G[c2 * ldj + mmr + c];
+                            K[e] = sum;
+                        }
                 }
                 __syncthreads();
-                bool singular = false;
-                for (int k = 0; k < mmr; ++k) {
-                    int piv = k;
-                    double best = fabs(G[k * ldg + k]);
-                    for (int i = k + 1; i < mmr; ++i) {
-                        double v = fabs(G[i * ldg + k]);
-                        if (v > best) { best = v; piv = i; }
-                    }
-                    if (!(best > 0.0)) { singular = true; break; }
-                    __syncthreads();
-                    if (piv != k)
-                        for (int c = tid; c < 2 * mmr; c += NTHREADS) {
-                            double t0 = G[k * ldg + c]; G[k * ldg + c] = G[piv * ldg + c]; G[piv * ldg + c] = t0;
-                        }
-                    __syncthreads();
-                    double pv = G[k * ldg + k];
-                    __syncthreads();
-                    for (int c = tid; c < 2 * mmr; c += NTHREADS) G[k * ldg + c] = G[k * ldg + c] / pv;
-                    __syncthreads();
-                    for (int r = tid; r < mmr; r += NTHREADS) {
-                        if (r == k) continue;
-                        double f = G[r * ldg + k];
-                        for (int c = 0; c < 2 * mmr; ++c) G[r * ldg + c] -= f * G[k * ldg + c];
-                    }
-                    __syncthreads();
-                }
+                SLK_STAMP(8);
                 if (singular) {
                     status |= SLK_ST_SINGULAR;
                 } else {
-                    // K = covXZ * S^-1 (:257)
-                    for (int e = tid; e < N * mmr; e += NTHREADS) {
-                        int t = e % N, c = e / N;
-                        double sum = 0.0;
-                        for (int c2 = 0; c2 < mmr; ++c2) sum += Pxz[t + N * idx[c2]] * G[c2 * ldg + mmr + c];
-                        K[e] = sum;
-                    }
-                    __syncthreads();
-                    // delta = K * innovation (:263), KS = K * S
-                    for (int e = tid; e < N * mmr; e += NTHREADS) {
-                        int t = e % N, c = e / N;
-                        double sum = 0.0;
-                        for (int c2 = 0; c2 < mmr; ++c2) sum += K[t + N * c2] * Sm[idx[c2] + m * idx[c]];
-                        KS[e] = sum;
-                    }
+                    // delta = K * innovation (:263)
                     for (int t = tid; t < N; t += NTHREADS) {
                         double sum = 0.0;
                         for (int c = 0; c < mmr; ++c) sum += K[t + N * c] * innov[idx[c]];
                         delta[t] = sum;
                     }
-                    __syncthreads();
-                    // Pk -= K S K^T (:262), lower triangle; P itself = strict upper triangle + pdiag
-                    for (int j = wave; j < N; j += NW)
-                        for (int i = j + lane; i < N; i += 64) {
-                            double p = (i == j) ? pdiag[i] : A[j + i * lda];
-                            double sum = 0.0;
-                            for (int c = 0; c < mmr; ++c) sum += KS[i + N * c] * K[j + N * c];
-                            A[i + j * lda] = p - sum;
-                        }
-                    __syncthreads();
-                    // ---- applyDelta (:263 -> :659-666): second Cholesky, re-drawn sigma points
-                    fail = chol_lower_inplace<NTHREADS>(A, N, lda, tid);
+                    SLK_STAMP(9);
+                    SLK_STAMP(10);
+                    // ---- Pk -= K S K^T (:262) fused into the load of applyDelta's Cholesky (:263 -> :659-662):
+                    // K S = covXZ, so the downdated lower triangle is P(i,j) - sum_c covXZ(i,c) K(j,c);
+                    // P itself still sits in the strict upper triangle of A and in pdiag.
+                    fail = chol_lower_regs<NTHREADS, SDN>(A, N, lda, colbuf, tid, [&](int i, int j) {
+                        double p = (i == j) ? pdiag[i] : A[j + i * lda];
+                        double sum = 0.0;
+                        for (int c = 0; c < mmr; ++c) sum += Pxz[i + N * idx[c]] * K[j + N * c];
+                        return p - sum;
+                    });
+                    SLK_STAMP(11);
                     if (fail >= 0) {
                         status |= SLK_ST_LLT_FAIL;
                     } else {
-                        double *Drot = pool;                              // [3*nso3][SP] rotation rows of X_i [-] ref
-                        double *Dp = pool + round_up(3 * nso3 * SP, 2);   // [KP][LDD] panel
+                        // ---- re-drawn sigma points, manifold mean (:664 -> :499-525), covariance (:665)
+                        double *DR = pool;                                // rotation deviations, 3 per stored item
+                        double *Dp = pool + round_up(3 * cv.W, 2);        // [2][KP][LDD] panels
+                        const int W = cv.W;
                         // reference = X[0] = mu + delta (:501)
                         for (int t = tid; t < N; t += NTHREADS) {
                             int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
@@ -589,29 +749,39 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
                             stq(ref + so3_soff(L, b), sigma_quat(L, mu, A, lda, delta, b, sig_of(0)));
                         __syncthreads();
                         int it = 0;
-                        double norm;
-                        do {                                              // :507-516
-                            for (int e = tid; e < S * nso3; e += NTHREADS) {
-                                int i = e % S, b = e / S;
+                        double norm = 0.0;
+                        bool final_pass = false;
+                        for (;;) {                                        // :507-516, then one pass against the final mean
+                            // rotation blocks of X_i [-] ref, only the sigma points whose block differs from X_0's
+                            for (int w = tid; w < W; w += NTHREADS) {
+                                int b = 0;
+                                while (w >= roff[b + 1]) ++b;
+                                int i = w - roff[b];
                                 Quat q = sigma_quat(L, mu, A, lda, delta, b, sig_of(i));
                                 double dx, dy, dz;
                                 so3_boxminus(q, ldq(ref + so3_soff(L, b)), dx, dy, dz);
-                                Drot[(3 * b) * SP + i] = dx;
-                                Drot[(3 * b + 1) * SP + i] = dy;
-                                Drot[(3 * b + 2) * SP + i] = dz;
+                                DR[3 * w] = dx; DR[3 * w + 1] = dy; DR[3 * w + 2] = dz;
                             }
                             __syncthreads();
-                            for (int t = tid; t < N; t += NTHREADS) {
-                                int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
-                                double sum = 0.0;
+                            if (final_pass) break;
+                            // mean_delta = sum_i (X_i [-] ref) / S, 4 lanes per tangent row
+                            for (int t = tid / 4; t < N; t += NTHREADS / 4) {
+                                int blk = 0, comp = 0, s = t2s(L, t, blk, comp), sub = tid & 3;
+                                double sum;
                                 if (s >= 0) {
-                                    double m0 = mu[s], r0 = ref[s];
-                                    for (int i = 0; i < S; ++i) sum += (m0 + pert(A, lda, delta, t, sig_of(i))) - r0;
+                                    double m0 = mu[s], r0 = ref[s], dl = delta[t];
+                                    sum = group_sum<4>(sub, t + 1, [&](int j) {
+                                        double l = A[t + j * lda];
+                                        return ((m0 + (dl + l)) - r0) + ((m0 + (dl - l)) - r0);
+                                    });
+                                    sum += (double)(S - 2 * (t + 1)) * ((m0 + dl) - r0);
                                 } else {
-                                    const double *row = Drot + (3 * blk + comp) * SP;
-                                    for (int i = 0; i < S; ++i) sum += row[i];
+                                    int cnt = roff[blk + 1] - roff[blk];
+                                    const double *row = DR + 3 * roff[blk] + comp;
+                                    sum = group_sum<4>(sub, cnt, [&](int i) { return row[3 * i]; });
+                                    sum += (double)(S - cnt) * row[0];
                                 }
-                                md[t] = sum / (double)S;
+                                if (sub == 0) md[t] = sum / (double)S;
                             }
                             __syncthreads();
                             double n2 = 0.0;
@@ -626,50 +796,77 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
                                 stq(ref + so, qmul(ldq(ref + so), so3_exp(md[to], md[to + 1], md[to + 2])));
                             }
                             __syncthreads();
-                        } while (norm > 1e-6 && ++it < 10000);
-                        if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
-                        // rotation rows of D = X_i [-] mu+ (:584)
-                        for (int e = tid; e < S * nso3; e += NTHREADS) {
-                            int i = e % S, b = e / S;
-                            Quat q = sigma_quat(L, mu, A, lda, delta, b, sig_of(i));
-                            double dx, dy, dz;
-                            so3_boxminus(q, ldq(ref + so3_soff(L, b)), dx, dy, dz);
-                            Drot[(3 * b) * SP + i] = dx;
-                            Drot[(3 * b + 1) * SP + i] = dy;
-                            Drot[(3 * b + 2) * SP + i] = dz;
+                            if (!(norm > 1e-6 && ++it < 10000)) final_pass = true;
                         }
-                        __syncthreads();
-                        // P+ = 1/2 D D^T on the fp64 matrix cores
+                        if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
+                        SLK_STAMP(12);
+                        SLK_NOTE(20, it + 1);
+                        SLK_STAMP(13);
+                        // ---- P+ = 1/2 D D^T on the fp64 matrix cores, D generated panel by panel
                         constexpr int TN = 16 * NT;
+                        constexpr int RPT = (TN + 63) / 64;                 // rows of D handled per lane
                         constexpr int TPW = MfmaTiles<NT, NW, 0>::TPW;
+                        // per-lane constants of its D rows: vector rows read L, rotation rows read DR
+                        int rkind[RPT], roffs[RPT], rcnt[RPT];
+                        double rm[RPT], rd[RPT], rr[RPT];
+#pragma unroll
+                        for (int q = 0; q < RPT; ++q) {
+                            int t = lane + 64 * q, blk = 0, comp = 0;
+                            rkind[q] = 0; roffs[q] = 0; rcnt[q] = 0; rm[q] = 0.0; rd[q] = 0.0; rr[q] = 0.0;
+                            if (t < N) {
+                                int s = t2s(L, t, blk, comp);
+                                if (s >= 0) { rkind[q] = 1; roffs[q] = t; rm[q] = mu[s]; rd[q] = delta[t]; rr[q] = ref[s]; }
+                                else { rkind[q] = 2; roffs[q] = 3 * roff[blk] + comp; rcnt[q] = roff[blk + 1] - roff[blk]; }
+                            }
+                        }
                         d4 acc[TPW];
 #pragma unroll
                         for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-                        for (int p0 = 0; p0 < S; p0 += KP) {
-                            for (int e = tid; e < KP * TN; e += NTHREADS) {
-                                int t = e % TN, kk = e / TN, i = p0 + kk;
-                                double v = 0.0;
-                                if (t < N && i < S) {
-                                    int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
-                                    if (s >= 0) v = (mu[s] + pert(A, lda, delta, t, sig_of(i))) - ref[s];
-                                    else v = Drot[(3 * blk + comp) * SP + i];
+                        auto gen_panel = [&](int p0, double *Dq) {
+                            for (int kk = wave; kk < KP; kk += NW) {
+                                int i = p0 + kk;
+                                int j = (i - 1) >> 1;
+                                double sgn = (i & 1) ? 1.0 : -1.0;
+#pragma unroll
+                                for (int q = 0; q < RPT; ++q) {
+                                    int t = lane + 64 * q;
+                                    if (t < TN) {
+                                        double v = 0.0;
+                                        if (i < S) {
+                                            if (rkind[q] == 1) {
+                                                double l = (i > 0 && j <= t) ? sgn * A[roffs[q] + j * lda] : 0.0;
+                                                v = (rm[q] + (rd[q] + l)) - rr[q];
+                                            } else if (rkind[q] == 2) {
+                                                v = DR[roffs[q] + 3 * (i < rcnt[q] ? i : 0)];
+                                            }
+                                        }
+                                        Dq[kk * LDD + t] = v;
+                                    }
                                 }
-                                Dp[kk * LDD + t] = v;
                             }
-                            __syncthreads();
+                        };
+                        gen_panel(0, Dp);
+                        __syncthreads();
+                        int pb = 0;
+                        for (int p0 = 0; p0 < S; p0 += KP, pb ^= 1) {
+                            const double *Dc = Dp + pb * KP * LDD;
 #pragma unroll
                             for (int ks = 0; ks < KP / 4; ++ks) {
                                 double frag[NT];
 #pragma unroll
-                                for (int I = 0; I < NT; ++I) frag[I] = Dp[(4 * ks + (lane >> 4)) * LDD + 16 * I + (lane & 15)];
+                                for (int I = 0; I < NT; ++I) frag[I] = Dc[(4 * ks + (lane >> 4)) * LDD + 16 * I + (lane & 15)];
                                 MfmaTiles<NT, NW, 0>::run(frag, acc, wave);
                             }
+                            if (p0 + KP < S) gen_panel(p0 + KP, Dp + (pb ^ 1) * KP * LDD);
                             __syncthreads();
                         }
+                        SLK_STAMP(14);
                         MfmaTiles<NT, NW, 0>::store(A, lda, N, acc, wave, lane);
                         __syncthreads();
-                        for (int e = tid; e < N * N; e += NTHREADS) { int r = e % N, c = e / N; gP[e] = A[r + c * lda]; }
+                        for (int c = wave; c < N; c += NW)
+                            for (int r = lane; r < N; r += 64) gP[r + (size_t)c * N] = A[r + c * lda];
                         for (int e = tid; e < Nq; e += NTHREADS) gmean[e] = ref[e];
+                        SLK_STAMP(15);
                     }
                 }
             }

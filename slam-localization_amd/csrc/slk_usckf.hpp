@@ -7,50 +7,57 @@
 
 namespace slk {
 
-struct UCarve { int P, Lm, mu, small, pool, total; int lda, S; };
+struct UCarve { int P, Lm, mu, small, colbuf, pool, total; int lda, S; };
 
-__host__ __device__ inline UCarve carve_usckf(int N, int Nq, int m)
+__host__ __device__ inline UCarve carve_usckf(int N, int Nq, int m, int NT)
 {
     UCarve c;
     c.lda = N | 1;
     c.S = 2 * N + 1;
     int o = 0;
-    c.P = o;     o += round_up(N * c.lda, 2);
-    c.Lm = o;    o += round_up(N * c.lda, 2);
-    c.mu = o;    o += round_up(Nq, 2);
-    c.small = o; o += 64;
+    c.P = o;      o += round_up(N * c.lda, 2);
+    c.Lm = o;     o += round_up(N * c.lda, 2);
+    c.mu = o;     o += round_up(Nq, 2);
+    c.small = o;  o += 64;
+    c.colbuf = o; o += 2 * (16 * NT > 32 ? 16 * NT : 32);
     c.pool = o;
-    int upd = round_up(c.S * m, 2) + 3 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (2 * m + 1), 2)
+    int upd = round_up(c.S * m, 2) + 3 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (m + 1), 2)
               + 4 * round_up(m, 2) + round_up(N, 2);
     int pred = PRED_SCRATCH + 160 + 160 + 2 * round_up(12 * N, 2);
     c.total = o + (upd > pred ? upd : pred);
     return c;
 }
 
-template <int NTHREADS>
+template <int NT, int NTHREADS>
 __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int bidx = blockIdx.x, tid = threadIdx.x;
+    constexpr int NW = NTHREADS / 64;
+    constexpr int GD = Grid<NTHREADS>::GD;
+    constexpr int SDN = (16 * NT + GD - 1) / GD;
+    constexpr int SDM = (MAXM + GD - 1) / GD;
+    const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Lay L = a.lay;
     const int N = L.N, Nq = L.Nq, m = a.m;
-    const UCarve cv = carve_usckf(N, Nq, m);
+    const UCarve cv = carve_usckf(N, Nq, m, NT);
     const int lda = cv.lda, S = cv.S;
-    double *P = smem + cv.P, *Lm = smem + cv.Lm, *mu = smem + cv.mu, *pool = smem + cv.pool;
+    double *P = smem + cv.P, *Lm = smem + cv.Lm, *mu = smem + cv.mu, *colbuf = smem + cv.colbuf, *pool = smem + cv.pool;
     int *ish = reinterpret_cast<int *>(smem + cv.small);
     double *gmean = a.mean + (size_t)bidx * Nq;
     double *gP = a.P + (size_t)bidx * N * N;
     int status = 0;
     if (a.do_update && tid == 0) a.outliers[bidx] = 0u;
+    if (tid == 0) ish[42] = 0;
 
     for (int e = tid; e < Nq; e += NTHREADS) mu[e] = gmean[e];
-    for (int e = tid; e < N * N; e += NTHREADS) { int r = e % N, c = e / N; P[r + c * lda] = gP[e]; }
+    for (int c = wave; c < N; c += NW)
+        for (int r = lane; r < N; r += 64) P[r + c * lda] = gP[r + (size_t)c * N];
     __syncthreads();
 
     if (a.do_predict || a.emit == 1) {
         // ---- Usckf::predict, Usckf.hpp:107-244
         double *Pblk = pool, *Pn = pool + 160, *Pxy = pool + 320, *Fk = pool + 480, *scr = pool + 640;
-        double *RB = pool + 640 + 672;             // old rows 24..35 of P: 12 x N (ld 12)
+        double *RB = pool + 640 + 800;             // old rows 24..35 of P: 12 x N (ld 12)
         double *CB = RB + round_up(12 * N, 2);     // old cols 24..35 of P: N x 12 (ld N)
         for (int e = tid; e < 144; e += NTHREADS) { int r = e % 12, c = e / 12; Pblk[r + c * 13] = P[(24 + r) + (24 + c) * lda]; }
         __syncthreads();
@@ -105,7 +112,8 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
             }
             __syncthreads();
             if (!a.do_update) {
-                for (int e = tid; e < N * N; e += NTHREADS) { int r = e % N, c = e / N; gP[e] = P[r + c * lda]; }
+                for (int c = wave; c < N; c += NW)
+                    for (int r = lane; r < N; r += 64) gP[r + (size_t)c * N] = P[r + c * lda];
                 for (int e = tid; e < Nq; e += NTHREADS) gmean[e] = mu[e];
             }
         }
@@ -114,9 +122,7 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
 
     if (a.do_update || a.emit == 2) {
         // ---- Usckf::update, Usckf.hpp:246-308
-        for (int e = tid; e < N * N; e += NTHREADS) { int r = e % N, c = e / N; Lm[r + c * lda] = P[r + c * lda]; }
-        __syncthreads();
-        int fail = chol_lower_inplace<NTHREADS>(Lm, N, lda, tid);
+        int fail = chol_lower_regs<NTHREADS, SDN>(Lm, N, lda, colbuf, tid, [&](int i, int j) { return P[i + j * lda]; });
         bool applied = false;
         if (fail >= 0) {
             status |= SLK_ST_LLT_FAIL;
@@ -135,136 +141,67 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
             }
         } else {
             double *Z = pool;
-            double *Pxz = Z + round_up(S * m, 2);
+            double *DZ = Z + round_up(S * m, 2);
+            double *Pxz = DZ + round_up(N * m, 2);
             double *K = Pxz + round_up(N * m, 2);
-            double *KS = K + round_up(N * m, 2);
-            double *Sm = KS + round_up(N * m, 2);
-            double *G = Sm + round_up(m * m, 2);
-            double *zbar = G + round_up(m * (2 * m + 1), 2);
+            double *Sm = K + round_up(N * m, 2);
+            double *G = Sm + round_up(m * m, 2);                 // Cholesky factor of S (ld m+1)
+            double *zbar = G + round_up(m * (m + 1), 2);
             double *innov = zbar + round_up(m, 2);
-            double *dlt = innov + 2 * round_up(m, 2);
-            const double *mp = a.mp ? a.mp + (size_t)bidx * a.mp_stride : nullptr;
-            if (a.mm == SLK_MODEL_EXTERNAL) {
-                const double *Ze = a.Zext + (size_t)bidx * S * m;
-                for (int e = tid; e < S * m; e += NTHREADS) Z[e] = Ze[e];
-            } else {
-                int nf = measure_features(a.mm, m);
-                for (int e = tid; e < S * nf; e += NTHREADS) {
-                    int f = e % nf, i = e / nf;
-                    measure_item(a, L, mp, mu, Lm, lda, i, f, Z + i * m);
-                }
-            }
-            __syncthreads();
-            for (int r = tid; r < m; r += NTHREADS) {                   // meanZ :280, innovation :290
-                double sum = 0.0;
-                for (int i = 0; i < S; ++i) sum += Z[i * m + r];
-                double zb = sum / (double)S;
-                zbar[r] = zb;
-                innov[r] = a.z[(size_t)bidx * m + r] - zb;
-            }
-            __syncthreads();
-            const double *R = a.R + (size_t)bidx * a.r_stride;
-            for (int e = tid; e < m * m; e += NTHREADS) {               // S :282
-                int r = e % m, c = e / m;
-                double zr = zbar[r], zc = zbar[c], sum = 0.0;
-                for (int i = 0; i < S; ++i) sum += (Z[i * m + r] - zr) * (Z[i * m + c] - zc);
-                Sm[e] = 0.5 * sum + R[e];
-            }
-            for (int e = tid; e < N * m; e += NTHREADS) {               // covXZ :283 -> :714-737
-                int t = e % N, r = e / N, blk = -1, comp = 0;
-                int s = t2s(L, t, blk, comp);
-                double sum = 0.0;
-                if (s >= 0) {
-                    for (int j = 0; j <= t; ++j) sum += Lm[t + j * lda] * (Z[(2 * j + 1) * m + r] - Z[(2 * j + 2) * m + r]);
-                } else {
-                    int t0 = t - comp;
-                    for (int j = 0; j <= t; ++j) {
-                        double v0 = Lz(Lm, lda, t0, j), v1 = Lz(Lm, lda, t0 + 1, j), v2 = Lz(Lm, lda, t0 + 2, j);
-                        double th = sqrt(v0 * v0 + v1 * v1 + v2 * v2), w = 1.0;
-                        if (th >= 3.141592653589793) w = 2.0 * atan(tan(0.5 * th)) / th;
-                        sum += w * Lm[t + j * lda] * (Z[(2 * j + 1) * m + r] - Z[(2 * j + 2) * m + r]);
-                    }
-                }
-                Pxz[e] = 0.5 * sum;
-            }
-            __syncthreads();
-            // S^-1 (:285-286) by Gauss-Jordan with partial pivoting
-            const int ldg = 2 * m + 1;
-            for (int e = tid; e < m * m; e += NTHREADS) {
-                int r = e % m, c = e / m;
-                G[r * ldg + c] = Sm[r + m * c];
-                G[r * ldg + m + c] = (r == c) ? 1.0 : 0.0;
-            }
-            __syncthreads();
-            bool singular = false;
-            for (int k = 0; k < m; ++k) {
-                int piv = k;
-                double best = fabs(G[k * ldg + k]);
-                for (int i = k + 1; i < m; ++i) {
-                    double v = fabs(G[i * ldg + k]);
-                    if (v > best) { best = v; piv = i; }
-                }
-                if (!(best > 0.0)) { singular = true; break; }
-                __syncthreads();
-                if (piv != k)
-                    for (int c = tid; c < 2 * m; c += NTHREADS) {
-                        double t0 = G[k * ldg + c]; G[k * ldg + c] = G[piv * ldg + c]; G[piv * ldg + c] = t0;
-                    }
-                __syncthreads();
-                double pv = G[k * ldg + k];
-                __syncthreads();
-                for (int c = tid; c < 2 * m; c += NTHREADS) G[k * ldg + c] = G[k * ldg + c] / pv;
-                __syncthreads();
-                for (int r = tid; r < m; r += NTHREADS) {
-                    if (r == k) continue;
-                    double f = G[r * ldg + k];
-                    for (int c = 0; c < 2 * m; ++c) G[r * ldg + c] -= f * G[k * ldg + c];
-                }
-                __syncthreads();
-            }
-            if (singular) {
+            double *wv = innov + round_up(m, 2);                 // Ls^-1 innovation
+            double *dlt = wv + 2 * round_up(m, 2);
+            measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lm, lda, Z, DZ, Pxz, Sm, zbar, innov, &ish[42]);
+            // S^-1 (:285-286): S = 1/2 dZ dZ^T + R is SPD for a valid R -> Cholesky, row-wise solves
+            const int ldg = m + 1;
+            int sfail = chol_lower_regs<NTHREADS, SDM>(G, m, ldg, colbuf, tid, [&](int i, int j) { return Sm[i + m * j]; });
+            if (sfail >= 0) {
                 status |= SLK_ST_SINGULAR;
             } else {
-                for (int e = tid; e < N * m; e += NTHREADS) {           // K = covXZ * S^-1 :288
-                    int t = e % N, c = e / N;
-                    double sum = 0.0;
-                    for (int c2 = 0; c2 < m; ++c2) sum += Pxz[t + N * c2] * G[c2 * ldg + m + c];
-                    K[e] = sum;
+                for (int t = tid; t < N; t += NTHREADS) {             // K = covXZ * S^-1 :288
+                    for (int c = 0; c < m; ++c) {
+                        double sum = Pxz[t + N * c];
+                        for (int p = 0; p < c; ++p) sum -= G[c + p * ldg] * K[t + N * p];
+                        K[t + N * c] = sum / G[c + c * ldg];
+                    }
+                    for (int c = m - 1; c >= 0; --c) {
+                        double sum = K[t + N * c];
+                        for (int p = c + 1; p < m; ++p) sum -= G[p + c * ldg] * K[t + N * p];
+                        K[t + N * c] = sum / G[c + c * ldg];
+                    }
                 }
-                double d2 = 0.0;                                        // mahalanobis2 :292
-                for (int i = 0; i < m; ++i) {
-                    double s = 0.0;
-                    for (int j = 0; j < m; ++j) s += G[i * ldg + m + j] * innov[j];
-                    d2 += innov[i] * s;
-                }
-                bool ok = true;
-                if (a.gate > 0) {
-                    const double thr[10] = {0, 3.84, 5.99, 7.81, 9.49, 11.07, 12.59, 14.07, 15.51, 16.92};
-                    ok = (a.gate <= 9) ? (d2 < thr[a.gate]) : false;   // Usckf.hpp:794-855
+                if (tid == 0) {                                        // mahalanobis2 = |Ls^-1 innovation|^2 :292
+                    double d2 = 0.0;
+                    for (int c = 0; c < m; ++c) {
+                        double sum = innov[c];
+                        for (int p = 0; p < c; ++p) sum -= G[c + p * ldg] * wv[p];
+                        wv[c] = sum / G[c + c * ldg];
+                        d2 += wv[c] * wv[c];
+                    }
+                    bool ok = true;
+                    if (a.gate > 0) {
+                        const double thr[10] = {0, 3.84, 5.99, 7.81, 9.49, 11.07, 12.59, 14.07, 15.51, 16.92};
+                        ok = (a.gate <= 9) ? (d2 < thr[a.gate]) : false;   // Usckf.hpp:794-855
+                    }
+                    ish[40] = ok ? 1 : 0;
                 }
                 __syncthreads();
-                if (!ok) {
+                if (!ish[40]) {
                     if (tid == 0) a.outliers[bidx] = 1u;
                     status |= SLK_ST_ALL_REJECTED;
                 } else {
-                    for (int e = tid; e < N * m; e += NTHREADS) {
-                        int t = e % N, c = e / N;
-                        double sum = 0.0;
-                        for (int c2 = 0; c2 < m; ++c2) sum += K[t + N * c2] * Sm[c2 + m * c];
-                        KS[e] = sum;
-                    }
                     for (int t = tid; t < N; t += NTHREADS) {
                         double sum = 0.0;
                         for (int c = 0; c < m; ++c) sum += K[t + N * c] * innov[c];
                         dlt[t] = sum;
                     }
+                    // Pk -= K S K^T (:296); K S = covXZ
+                    for (int j = wave; j < N; j += NW)
+                        for (int i = lane; i < N; i += 64) {
+                            double sum = 0.0;
+                            for (int c = 0; c < m; ++c) sum += Pxz[i + N * c] * K[j + N * c];
+                            P[i + j * lda] -= sum;
+                        }
                     __syncthreads();
-                    for (int e = tid; e < N * N; e += NTHREADS) {       // Pk -= K S K^T :296
-                        int i = e % N, j = e / N;
-                        double sum = 0.0;
-                        for (int c = 0; c < m; ++c) sum += KS[i + N * c] * K[j + N * c];
-                        P[i + j * lda] -= sum;
-                    }
                     // mu_state = mu_state + state(K * innovation) :299-301 (set() then boxplus through
                     // getVectorizedState(): exp/log round trip == direct boxplus for |rotation| < pi)
                     for (int t = tid; t < N; t += NTHREADS) {
@@ -281,11 +218,11 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
         }
         __syncthreads();
         if (a.emit != 2 && (applied || a.do_predict)) {
-            for (int e = tid; e < N * N; e += NTHREADS) { int r = e % N, c = e / N; gP[e] = P[r + c * lda]; }
+            for (int c = wave; c < N; c += NW)
+                for (int r = lane; r < N; r += 64) gP[r + (size_t)c * N] = P[r + c * lda];
             for (int e = tid; e < Nq; e += NTHREADS) gmean[e] = mu[e];
         }
     }
-    (void)ish;
     if (tid == 0 && status) atomicOr(a.status + bidx, status);
 }
 
