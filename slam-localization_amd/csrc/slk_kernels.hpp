@@ -1,9 +1,10 @@
 // slk_kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4) for the sigma-point Kalman
 // hot path of localization::Msckf / localization::Usckf (reference src/filters/Msckf.hpp,
-// Usckf.hpp).  One workgroup owns one filter; the filter's covariance lives in LDS for the
-// whole step (Cholesky -> sigma points -> measurement map -> moments -> gain -> downdate ->
-// second Cholesky -> manifold mean -> fp64 MFMA covariance rebuild), HBM sees each of
-// {mean, P} once in and once out.
+// Usckf.hpp).  One workgroup owns one filter.  Per step HBM sees the lower triangle of P twice
+// (second time from L2 / Infinity Cache) and {mean, P} once out; everything in between lives in
+// registers and LDS: register-resident Cholesky -> packed factor in LDS -> sigma points ->
+// measurement map -> moments -> gain -> downdate fused into the second Cholesky -> manifold mean
+// -> fp64 MFMA covariance rebuild.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -83,12 +84,6 @@ __host__ __device__ __forceinline__ void pose_of(const Lay &L, int c, int &tp, i
     } else { tp = 12 * c; sp = 13 * c; b = c; }
 }
 
-// ------------------------------------------------------------------ LDS carve (in doubles)
-struct Carve {
-    int A, pdiag, mu, ref, delta, md, small, colbuf, pool, total;
-    int lda, S, LDD, TN, W;   // W = stored rotation-row items (sum over blocks of 2*(toff+3)+1)
-};
-
 __host__ __device__ inline int round_up(int x, int q) { return (x + q - 1) / q * q; }
 
 // number of sigma points whose SO(3) block b differs from X_0's: columns j <= toff_b + 2 of the
@@ -99,42 +94,57 @@ __host__ __device__ __forceinline__ int rot_count(const Lay &L, int b)
     return c < S ? c : S;
 }
 
+// ------------------------------------------------------------------ packed lower-triangular factor
+// column j holds rows j..n-1 contiguously: element (i, j), i >= j, at j*(2n - j + 1)/2 + (i - j)
+__host__ __device__ __forceinline__ int pk(int n, int i, int j) { return ((j * (2 * n - j + 1)) >> 1) + (i - j); }
+__host__ __device__ __forceinline__ int pk_size(int n) { return n * (n + 1) / 2; }
+__device__ __forceinline__ double Lz(const double *Lp, int n, int t, int j)
+{
+    return (j <= t) ? Lp[pk(n, t, j)] : 0.0;
+}
+
+// ------------------------------------------------------------------ LDS carve (in doubles)
+struct Carve {
+    int Lp, mu, ref, delta, md, pn12, small, colbuf, pool, total;
+    int S, LDD, TN, W;   // W = rotation-row items that differ from X_0 (sum over blocks of rot_count)
+};
+
 __host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT)
 {
     const int N = L.N, Nq = L.Nq;
     Carve c;
-    c.lda = N | 1;
     c.S = 2 * N + 1;
     c.TN = 16 * NT;
     c.LDD = 16 * NT + ((NT & 1) ? 0 : 16);       // LDD % 32 == 16: the two 16-lane halves of a b64 read hit disjoint banks
     c.W = 0;
     for (int b = 0; b < L.nso3; ++b) c.W += rot_count(L, b);
     int o = 0;
-    c.A = o;      o += round_up(N * c.lda, 2);
-    c.pdiag = o;  o += round_up(N, 2);
+    c.Lp = o;     o += round_up(pk_size(N), 2);
     c.mu = o;     o += round_up(Nq, 2);
     c.ref = o;    o += round_up(Nq, 2);
     c.delta = o;  o += round_up(N, 2);
     c.md = o;     o += round_up(N, 2);
+    c.pn12 = o;   o += 144;
     c.small = o;  o += 96;
-    c.colbuf = o; o += 2 * (c.TN > 32 ? c.TN : 32);
+    c.colbuf = o; o += 4 * (c.TN > 32 ? c.TN : 32);
     c.pool = o;
     // measurement part: Z[S*m] DZ[N*m] Pxz[N*m] K[N*m] Sm[m*m] G[m*(2m+1)] zbar innov
     int upd1 = round_up(c.S * m, 2) + 3 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (2 * m + 1), 2)
                + 4 * round_up(m, 2);
-    // applyDelta part: DR[3*W] + double-buffered panel
-    int upd2 = round_up(3 * c.W, 2) + 2 * KP * c.LDD;
+    // applyDelta part: rotation deviations of the mean loop (3*W), then the double-buffered panels (aliased)
+    int upd2a = round_up(3 * c.W, 2) + round_up(3 * L.nso3, 2);
+    int upd2b = 2 * KP * c.LDD + round_up(3 * L.nso3, 2);
     int pool = PRED_SCRATCH;
     if (upd1 > pool) pool = upd1;
-    if (upd2 > pool) pool = upd2;
+    if (upd2a > pool) pool = upd2a;
+    if (upd2b > pool) pool = upd2b;
     c.total = o + pool;
     return c;
 }
 
 // ------------------------------------------------------------------ implicit sigma points
 // generateSigmaPoints (Msckf.hpp:407-431 / :442-468): X0 = mu + delta, X(2j+1) = mu + (delta + L.col(j)),
-// X(2j+2) = mu + (delta - L.col(j)).  L is the lower triangle of the in-place factor; the strict
-// upper triangle of the array holds other data and must read as 0.
+// X(2j+2) = mu + (delta - L.col(j)); L = packed lower factor.
 struct Sig { int j; double sgn; };
 __device__ __forceinline__ Sig sig_of(int i)
 {
@@ -143,91 +153,110 @@ __device__ __forceinline__ Sig sig_of(int i)
     s.sgn = (i == 0) ? 0.0 : ((i & 1) ? 1.0 : -1.0);
     return s;
 }
-__device__ __forceinline__ double Lz(const double *A, int lda, int t, int j)
+__device__ __forceinline__ double pert(const double *Lp, int n, const double *delta, int t, const Sig &s)
 {
-    return (j <= t) ? A[t + j * lda] : 0.0;
-}
-__device__ __forceinline__ double pert(const double *A, int lda, const double *delta, int t, const Sig &s)
-{
-    double l = (s.sgn != 0.0) ? s.sgn * Lz(A, lda, t, s.j) : 0.0;
+    double l = (s.sgn != 0.0) ? s.sgn * Lz(Lp, n, t, s.j) : 0.0;
     return delta ? (delta[t] + l) : l;
 }
-__device__ __forceinline__ Quat sigma_quat(const Lay &L, const double *mu, const double *A, int lda,
+__device__ __forceinline__ Quat sigma_quat(const Lay &L, const double *mu, const double *Lp,
                                            const double *delta, int b, const Sig &s)
 {
     int to = so3_toff(L, b);
     return qmul(ldq(mu + so3_soff(L, b)),
-                so3_exp(pert(A, lda, delta, to, s), pert(A, lda, delta, to + 1, s), pert(A, lda, delta, to + 2, s)));
+                so3_exp(pert(Lp, L.N, delta, to, s), pert(Lp, L.N, delta, to + 1, s), pert(Lp, L.N, delta, to + 2, s)));
 }
-
 
 // ------------------------------------------------------------------ register-resident Cholesky
 // Lower Cholesky of an n x n matrix with the trailing matrix held in REGISTERS, block-cyclic over a
 // GD x GD thread grid (thread (ti,tj) owns elements i = ti + GD*sa, j = tj + GD*sb).  Per column: the
 // owners publish the raw column through a double-buffered LDS vector, ONE barrier, everybody applies
-// a_ij -= c_i c_j / d.  The finished factor is written to the lower triangle of A (the strict upper
-// triangle of A is never touched).  init(i, j) supplies the initial lower-triangle element, so the
-// covariance downdate is fused into the load.  Returns -1 or the first non-positive pivot (uniform).
+// a_ij -= c_i c_j / d.  The pivot uses v_rsq_f64 + two Newton steps instead of sqrt and two divisions
+// (they were the critical path).  The finished factor goes to the packed array Lp.  init(i, j)
+// supplies the initial lower-triangle element (global memory, or P minus the gain downdate), so no
+// copy of P is staged in LDS.  Returns -1 or the first non-positive pivot (same in every thread).
 // Eigen::LLT in the reference never has its info() read (Msckf.hpp:412-413, Usckf.hpp:537-538).
 template <int NTHREADS> struct Grid { static constexpr int GD = (NTHREADS >= 256) ? 16 : 8; };
 
-// one GD-wide block of columns, KB = compile-time slot index of the pivot columns
+__device__ __forceinline__ void rsqrt_pivot(double d, double &sq, double &rs)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    double h = 0.5 * d;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    double g = d * y;
+    g = fma(0.5 * y, fma(-g, g, d), g);     // sqrt(d) to ~1 ulp
+    sq = g;
+    rs = y;
+}
+
+// Two pivot columns per barrier (rank-2 step): columns k and k+1 are published raw, every thread
+// redoes the tiny 2x2 pivot algebra itself, then a_ij -= l0_i l0_j + l1_i l1_j.  Slots with i <= k+1 or
+// j <= k+1 are dead after the step, so no masking of the LDS reads is needed (garbage only ever
+// reaches dead slots); an odd n is padded with a unit diagonal element by chol_packed.
 template <int NTHREADS, int SD, int KB>
 struct CholCols {
-    __device__ __forceinline__ static void run(double (&a)[SD][SD], double *A, int n, int lda, double *colbuf,
+    __device__ __forceinline__ static void run(double (&a)[SD][SD], double *Lp, int n, double *colbuf,
                                                int ti, int tj, bool active, int &fail)
     {
         if constexpr (KB < SD) {
             constexpr int GD = Grid<NTHREADS>::GD;
             constexpr int CB = SD * GD;
             if (fail < 0) {
-                for (int kt = 0; kt < GD; ++kt) {
+                for (int kt = 0; kt < GD; kt += 2) {
                     const int k = KB * GD + kt;
                     if (k >= n) break;
-                    double *buf = colbuf + (k & 1) * CB;
-                    if (active && tj == kt) {
+                    double *buf0 = colbuf + ((k >> 1) & 1) * (2 * CB), *buf1 = buf0 + CB;
+                    if (active && (tj == kt || tj == kt + 1)) {
+                        double *bw = (tj == kt) ? buf0 : buf1;
 #pragma unroll
-                        for (int sa = 0; sa < SD; ++sa) {
-                            int i = ti + GD * sa;
-                            if (i >= k && i < n) buf[i] = a[sa][KB];
-                        }
+                        for (int sa = 0; sa < SD; ++sa) bw[ti + GD * sa] = a[sa][KB];
                     }
                     __syncthreads();
-                    const double d = buf[k];
-                    if (!(d > 0.0)) { fail = k; break; }
-                    const double sq = sqrt(d), inv = 1.0 / d;
-                    if (active && tj == kt) {
+                    const double d0 = buf0[k], e01 = buf0[k + 1], d1raw = buf1[k + 1];
+                    double li0[SD], li1[SD], lj0[SD], lj1[SD];
 #pragma unroll
-                        for (int sa = 0; sa < SD; ++sa) {
-                            int i = ti + GD * sa;
-                            if (i > k && i < n) A[i + k * lda] = a[sa][KB] / sq;
-                            else if (i == k) A[k + k * lda] = sq;
+                    for (int sa = 0; sa < SD; ++sa) { li0[sa] = buf0[ti + GD * sa]; li1[sa] = buf1[ti + GD * sa]; }
+#pragma unroll
+                    for (int sb = KB; sb < SD; ++sb) { lj0[sb] = buf0[tj + GD * sb]; lj1[sb] = buf1[tj + GD * sb]; }
+                    if (!(d0 > 0.0)) { fail = k; break; }
+                    double sq0, r0, sq1, r1;
+                    rsqrt_pivot(d0, sq0, r0);
+                    const double l10 = e01 * r0;
+                    const double d1 = fma(-l10, l10, d1raw);
+                    if (!(d1 > 0.0)) { fail = k + 1; break; }
+                    rsqrt_pivot(d1, sq1, r1);
+#pragma unroll
+                    for (int sa = 0; sa < SD; ++sa) { li0[sa] *= r0; li1[sa] = fma(-li0[sa], l10, li1[sa]) * r1; }
+#pragma unroll
+                    for (int sb = KB; sb < SD; ++sb) { lj0[sb] *= r0; lj1[sb] = fma(-lj0[sb], l10, lj1[sb]) * r1; }
+                    if (active && (tj == kt || tj == kt + 1)) {
+                        const bool first = (tj == kt);
+                        const int kc = first ? k : k + 1;
+                        if (kc < n) {
+                            const int base = pk(n, kc, kc);
+                            const double sq = first ? sq0 : sq1;
+#pragma unroll
+                            for (int sa = 0; sa < SD; ++sa) {
+                                int i = ti + GD * sa;
+                                double v = (i == kc) ? sq : (first ? li0[sa] : li1[sa]);
+                                if (i >= kc && i < n) Lp[base + (i - kc)] = v;
+                            }
                         }
-                    }
-                    double ci[SD], cj[SD];
-#pragma unroll
-                    for (int sa = 0; sa < SD; ++sa) {
-                        int i = ti + GD * sa;
-                        ci[sa] = (i > k && i < n) ? buf[i] : 0.0;
-                    }
-#pragma unroll
-                    for (int sb = KB; sb < SD; ++sb) {
-                        int j = tj + GD * sb;
-                        cj[sb] = (j > k && j < n) ? buf[j] * inv : 0.0;
                     }
 #pragma unroll
                     for (int sa = 0; sa < SD; ++sa)
 #pragma unroll
-                        for (int sb = KB; sb < SD; ++sb) a[sa][sb] -= ci[sa] * cj[sb];
+                        for (int sb = KB; sb < SD; ++sb) a[sa][sb] -= fma(li0[sa], lj0[sb], li1[sa] * lj1[sb]);
                 }
             }
-            CholCols<NTHREADS, SD, KB + 1>::run(a, A, n, lda, colbuf, ti, tj, active, fail);
+            CholCols<NTHREADS, SD, KB + 1>::run(a, Lp, n, colbuf, ti, tj, active, fail);
         }
     }
 };
 
+// colbuf needs 4 * SD * GD doubles
 template <int NTHREADS, int SD, class InitFn>
-__device__ __forceinline__ int chol_lower_regs(double *A, int n, int lda, double *colbuf, int tid, InitFn init)
+__device__ __forceinline__ int chol_packed(double *Lp, int n, double *colbuf, int tid, InitFn init)
 {
     constexpr int GD = Grid<NTHREADS>::GD;
     const int ti = tid % GD, tj = tid / GD;
@@ -238,12 +267,12 @@ __device__ __forceinline__ int chol_lower_regs(double *A, int n, int lda, double
 #pragma unroll
         for (int sb = 0; sb < SD; ++sb) {
             int i = ti + GD * sa, j = tj + GD * sb;
-            a[sa][sb] = (active && i < n && j <= i) ? init(i, j) : 0.0;
+            a[sa][sb] = (active && i < n && j <= i) ? init(i, j) : ((i == n && j == n) ? 1.0 : 0.0);
         }
     int fail = -1;
-    CholCols<NTHREADS, SD, 0>::run(a, A, n, lda, colbuf, ti, tj, active, fail);
+    CholCols<NTHREADS, SD, 0>::run(a, Lp, n, colbuf, ti, tj, active, fail);
     __syncthreads();
-    return fail;
+    return (fail >= n) ? -1 : fail;
 }
 
 // ------------------------------------------------------------------ small reductions
@@ -253,6 +282,7 @@ template <int G, class TermFn>
 __device__ __forceinline__ double group_sum(int sub, int cnt, TermFn term)
 {
     double s = 0.0;
+#pragma unroll 4
     for (int i = sub; i < cnt; i += G) s += term(i);
 #pragma unroll
     for (int o = G / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -262,16 +292,17 @@ __device__ __forceinline__ double group_sum(int sub, int cnt, TermFn term)
 // ------------------------------------------------------------------ registered measurement models
 // one work item = (sigma point i, feature f); writes that feature's rows of Z[i*m + ...]
 __device__ __forceinline__ void measure_item(const KArgs &a, const Lay &L, const double *mp, const double *mu,
-                                             const double *A, int lda, int i, int f, double *Zrow)
+                                             const double *Lp, int i, int f, double *Zrow)
 {
+    const int n = L.N;
     Sig s = sig_of(i);
     if (a.mm == SLK_MM_FEATURE_PROJ) {
         int tp, sp, b;
         pose_of(L, (int)mp[4 * f + 3], tp, sp, b);
-        double px = mu[sp] + pert(A, lda, nullptr, tp, s);
-        double py = mu[sp + 1] + pert(A, lda, nullptr, tp + 1, s);
-        double pz = mu[sp + 2] + pert(A, lda, nullptr, tp + 2, s);
-        Quat q = sigma_quat(L, mu, A, lda, nullptr, b, s);
+        double px = mu[sp] + pert(Lp, n, nullptr, tp, s);
+        double py = mu[sp + 1] + pert(Lp, n, nullptr, tp + 1, s);
+        double pz = mu[sp + 2] + pert(Lp, n, nullptr, tp + 2, s);
+        Quat q = sigma_quat(L, mu, Lp, nullptr, b, s);
         double lx, ly, lz;
         qrot(qconj(q), mp[4 * f] - px, mp[4 * f + 1] - py, mp[4 * f + 2] - pz, lx, ly, lz);
         Zrow[2 * f] = lx / lz;
@@ -279,20 +310,20 @@ __device__ __forceinline__ void measure_item(const KArgs &a, const Lay &L, const
     } else if (a.mm == SLK_MM_POSE_POSITION) {
         int tp, sp, b;
         pose_of(L, (int)mp[0], tp, sp, b);
-        for (int c = 0; c < 3 && c < a.m; ++c) Zrow[c] = mu[sp + c] + pert(A, lda, nullptr, tp + c, s);
+        for (int c = 0; c < 3 && c < a.m; ++c) Zrow[c] = mu[sp + c] + pert(Lp, n, nullptr, tp + c, s);
     } else { // SLK_MM_VO_RELATIVE (Usckf layout): UsckfUnitTest.cpp:62-86, feature triple f
         double dk[3], di[3];
         for (int c = 0; c < 3; ++c) {
-            dk[c] = mu[c] + pert(A, lda, nullptr, c, s);
-            di[c] = mu[26 + c] + pert(A, lda, nullptr, 24 + c, s);
+            dk[c] = mu[c] + pert(Lp, n, nullptr, c, s);
+            di[c] = mu[26 + c] + pert(Lp, n, nullptr, 24 + c, s);
         }
-        Quat qk = sigma_quat(L, mu, A, lda, nullptr, 0, s), qi = sigma_quat(L, mu, A, lda, nullptr, 2, s);
+        Quat qk = sigma_quat(L, mu, Lp, nullptr, 0, s), qi = sigma_quat(L, mu, Lp, nullptr, 2, s);
         double rx, ry, rz;
         so3_boxminus(qk, qi, rx, ry, rz);               // delta_state = statek - statek_i
         Quat dq = so3_exp(rx, ry, rz);                  // ... assigned to a WSingleState: set()
-        double fx = mu[39 + 3 * f] + pert(A, lda, nullptr, 36 + 3 * f, s);
-        double fy = mu[39 + 3 * f + 1] + pert(A, lda, nullptr, 36 + 3 * f + 1, s);
-        double fz = mu[39 + 3 * f + 2] + pert(A, lda, nullptr, 36 + 3 * f + 2, s);
+        double fx = mu[39 + 3 * f] + pert(Lp, n, nullptr, 36 + 3 * f, s);
+        double fy = mu[39 + 3 * f + 1] + pert(Lp, n, nullptr, 36 + 3 * f + 1, s);
+        double fz = mu[39 + 3 * f + 2] + pert(Lp, n, nullptr, 36 + 3 * f + 2, s);
         double ox, oy, oz;
         qmat_apply(dq, fx, fy, fz, ox, oy, oz);
         Zrow[3 * f] = ox + (dk[0] - di[0]);
@@ -305,14 +336,13 @@ __host__ __device__ __forceinline__ int measure_features(int mm, int m)
     return mm == SLK_MM_FEATURE_PROJ ? m / 2 : (mm == SLK_MM_POSE_POSITION ? 1 : m / 3);
 }
 
-
 // ------------------------------------------------------------------ measurement moments
 // Z = h(X) over the implicit sigma points of (mu, L), mean_z, innovation, S = 1/2 dZ dZ^T + R and
 // covXZ = 1/2 sum (X_i [-] mu)(Z_i - mean_z)^T  (Msckf.hpp:231-239, Usckf.hpp:277-283).
-// Lf holds the Cholesky factor in its lower triangle (ld lda).  *flag must be 0 on entry.
+// Lp = packed Cholesky factor.  *flag must be 0 on entry.
 template <int NTHREADS>
 __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L, int bidx, int tid, const double *mu,
-                                                    const double *A, int lda, double *Z, double *DZ, double *Pxz,
+                                                    const double *Lp, double *Z, double *DZ, double *Pxz,
                                                     double *Sm, double *zbar, double *innov, int *flag)
 {
     const int N = L.N, m = a.m, S = 2 * N + 1, nso3 = L.nso3;
@@ -325,13 +355,13 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
         int nf = measure_features(a.mm, m);
         for (int e = tid; e < S * nf; e += NTHREADS) {
             int f = e % nf, i = e / nf;
-            measure_item(a, L, mp, mu, A, lda, i, f, Z + i * m);
+            measure_item(a, L, mp, mu, Lp, i, f, Z + i * m);
         }
     }
     // rotation columns of L longer than pi make log(exp(v)) wrap (MTK log uses atan): flag them
     for (int e = tid; e < N * nso3; e += NTHREADS) {
         int j = e % N, b = e / N, t0 = so3_toff(L, b);
-        double v0 = Lz(A, lda, t0, j), v1 = Lz(A, lda, t0 + 1, j), v2 = Lz(A, lda, t0 + 2, j);
+        double v0 = Lz(Lp, N, t0, j), v1 = Lz(Lp, N, t0 + 1, j), v2 = Lz(Lp, N, t0 + 2, j);
         if (v0 * v0 + v1 * v1 + v2 * v2 >= 9.869604401089358) *flag = 1;
     }
     __syncthreads();
@@ -365,17 +395,18 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
         int t = e % N, r = e / N;
         double sum = 0.0;
         if (!wrap) {
-            for (int j = 0; j <= t; ++j) sum += A[t + j * lda] * DZ[j * m + r];
+#pragma unroll 4
+            for (int j = 0; j <= t; ++j) sum += Lp[pk(N, t, j)] * DZ[j * m + r];
         } else {
             int blk = -1, comp = 0, s = t2s(L, t, blk, comp), t0 = t - comp;
             for (int j = 0; j <= t; ++j) {
                 double w = 1.0;
                 if (s < 0) {
-                    double v0 = Lz(A, lda, t0, j), v1 = Lz(A, lda, t0 + 1, j), v2 = Lz(A, lda, t0 + 2, j);
+                    double v0 = Lz(Lp, N, t0, j), v1 = Lz(Lp, N, t0 + 1, j), v2 = Lz(Lp, N, t0 + 2, j);
                     double th = sqrt(v0 * v0 + v1 * v1 + v2 * v2);
                     if (th >= 3.141592653589793) w = 2.0 * atan(tan(0.5 * th)) / th;
                 }
-                sum += w * A[t + j * lda] * DZ[j * m + r];
+                sum += w * Lp[pk(N, t, j)] * DZ[j * m + r];
             }
         }
         Pxz[e] = 0.5 * sum;
@@ -383,26 +414,26 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
     __syncthreads();
 }
 
-
 // ------------------------------------------------------------------ 12-DOF predict phase
 // Msckf.hpp:102-165 == Usckf.hpp:117-181: sigma points of the current State, process model map,
-// manifold mean, new Pk_i = cov + Q.  Pblk = 12x12 (ld 13) lower block of the covariance on entry,
-// Cholesky factor on exit (Usckf needs it for Fk); x13 = current State mean, replaced by the new
-// mean.  Pn (12x12, ld 12) receives the new block.  Returns 0 or status bits (uniform), -1 after a
-// sigma-point emission.  scratch (doubles): Ys[25*13] dbuf[25*12] refs[16] mdel[16] colbuf[64]
-template <int NTHREADS, bool WANT_PXY>
-__device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, double *Pblk, double *x13, double *Pn,
-                             double *scr, double *Pxy /* 12x12 ld 12, only if WANT_PXY */)
+// manifold mean, new Pk_i = cov + Q.  pin(i, j) = lower triangle of the 12x12 covariance block;
+// Lblk (packed, 78) receives its Cholesky factor (Usckf needs it for Fk); x13 = current State mean,
+// replaced by the new mean.  Pn (12x12, ld 12) receives the new block.  Returns 0 or status bits
+// (uniform), -1 after a sigma-point emission.
+// scratch (doubles): Ys[25*13] dbuf[25*12] refs[16] mdel[16] colbuf[128]
+template <int NTHREADS, bool WANT_PXY, class PinFn>
+__device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, PinFn pin, double *Lblk, double *x13,
+                                             double *Pn, double *scr, double *Pxy /* 12x12 ld 12, only if WANT_PXY */)
 {
     double *Ys = scr, *dbuf = scr + 25 * 13, *refs = dbuf + 25 * 12, *mdel = refs + 16, *cb = mdel + 16;
     constexpr int SD12 = (12 + Grid<NTHREADS>::GD - 1) / Grid<NTHREADS>::GD;
-    int fail = chol_lower_regs<NTHREADS, SD12>(Pblk, 12, 13, cb, tid, [&](int i, int j) { return Pblk[i + j * 13]; });
+    int fail = chol_packed<NTHREADS, SD12>(Lblk, 12, cb, tid, pin);
     if (fail >= 0) return SLK_ST_LLT_FAIL;
     const double *u = a.u ? a.u + (size_t)bidx * a.u_stride : nullptr;
     if (tid < 25) {
         Sig s = sig_of(tid);
         double v[12], x[13], y[13];
-        for (int t = 0; t < 12; ++t) v[t] = pert(Pblk, 13, nullptr, t, s);
+        for (int t = 0; t < 12; ++t) v[t] = pert(Lblk, 12, nullptr, t, s);
         state_boxplus(x13, v, x);
         if (a.emit == 1) {
             for (int c = 0; c < 13; ++c) a.Xout[((size_t)bidx * 25 + tid) * 13 + c] = x[c];
@@ -455,7 +486,7 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
             double sx = 0.0;
             for (int i = 1; i < 25; ++i) {
                 Sig s = sig_of(i);
-                sx += s.sgn * Lz(Pblk, 13, r, s.j) * dbuf[i * 12 + c];
+                sx += s.sgn * Lz(Lblk, 12, r, s.j) * dbuf[i * 12 + c];
             }
             Pxy[e] = 0.5 * sx;
         }
@@ -468,9 +499,10 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
 
 // ------------------------------------------------------------------ fp64 MFMA covariance rebuild
 // P+ = 1/2 * D * D^T (Msckf.hpp:574-589), D = N x S deviations streamed through LDS in panels of KP
-// sigma points.  v_mfma_f64_16x16x4_f64: lane l holds A[row l&15][k l>>4] and B[k l>>4][col l&15];
-// for D*D^T the A fragment of row-tile I equals the B fragment of column-tile I.  Result lane l,
-// register r: row (l>>4)+4r, col l&15.  Lower-triangle tiles only, dealt round-robin to the waves.
+// sigma points.  v_mfma_f64_16x16x4_f64 (64 cycles per SIMD, measured): lane l holds A[row l&15][k l>>4]
+// and B[k l>>4][col l&15]; for D*D^T the A fragment of row-tile I equals the B fragment of
+// column-tile I.  Result lane l, register r: row (l>>4)+4r, col l&15.  Lower-triangle tiles only,
+// dealt round-robin to the waves.
 template <int NT> struct TileMap {
     static constexpr int NTILES = NT * (NT + 1) / 2;
     __host__ __device__ static constexpr int row(int t) { int i = 0; while ((i + 1) * (i + 2) / 2 <= t) ++i; return i; }
@@ -489,7 +521,9 @@ struct MfmaTiles {
             MfmaTiles<NT, NW, T + 1>::run(frag, acc, wave);
         }
     }
-    __device__ __forceinline__ static void store(double *A, int lda, int N, const d4 (&acc)[TPW], int wave, int lane)
+    // accumulators -> global P (column-major, both triangles).  The tile is written transposed
+    // (P is symmetric), so that the 16 lanes of a row group store 128 contiguous bytes.
+    __device__ __forceinline__ static void store(double *gP, int N, const d4 (&acc)[TPW], int wave, int lane)
     {
         if constexpr (T < TileMap<NT>::NTILES) {
             if ((T % NW) == wave) {
@@ -500,12 +534,12 @@ struct MfmaTiles {
                     int rr = 16 * I + (lane >> 4) + 4 * r;
                     if (rr < N && c < N) {
                         double v = 0.5 * acc[T / NW][r];
-                        A[rr + c * lda] = v;
-                        if (I != J) A[c + rr * lda] = v;
+                        gP[c + (size_t)rr * N] = v;
+                        if (I != J) gP[rr + (size_t)c * N] = v;
                     }
                 }
             }
-            MfmaTiles<NT, NW, T + 1>::store(A, lda, N, acc, wave, lane);
+            MfmaTiles<NT, NW, T + 1>::store(gP, N, acc, wave, lane);
         }
     }
 };
@@ -513,7 +547,7 @@ struct MfmaTiles {
 // ------------------------------------------------------------------ the Msckf step kernel
 // predict (optional) + UKF update with applyDelta (optional), one workgroup per filter.
 template <int NT, int NTHREADS>
-__global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
+__global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_step_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NTHREADS / 64;
@@ -524,68 +558,57 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
     const Lay L = a.lay;
     const int N = L.N, Nq = L.Nq, m = a.m, nso3 = L.nso3;
     const Carve cv = carve_step(L, m, NT);
-    const int lda = cv.lda, S = cv.S, LDD = cv.LDD;
-    double *A = smem + cv.A, *pdiag = smem + cv.pdiag, *mu = smem + cv.mu, *ref = smem + cv.ref;
+    const int S = cv.S, LDD = cv.LDD;
+    double *Lp = smem + cv.Lp, *mu = smem + cv.mu, *ref = smem + cv.ref, *pn12 = smem + cv.pn12;
     double *delta = smem + cv.delta, *md = smem + cv.md, *colbuf = smem + cv.colbuf, *pool = smem + cv.pool;
-    int *ish = reinterpret_cast<int *>(smem + cv.small);      // [0..MAXM) idx, [40] count, [41] outliers, [42] flag, [48..) rot offsets
-    int *roff = ish + 48;                                     // nso3 + 1 prefix offsets of the stored rotation items
+    int *ish = reinterpret_cast<int *>(smem + cv.small);      // [0..MAXM) idx, [40] count, [41] outliers, [42] flag, [43] predicted
+    int *roff = ish + 48;                                     // nso3 + 1 prefix offsets of the rotation items
     double *gmean = a.mean + (size_t)bidx * Nq;
     double *gP = a.P + (size_t)bidx * N * N;
     int status = 0;
     if (a.do_update && tid == 0) a.outliers[bidx] = 0u;
     SLK_STAMP(0);
 
-    // ---- load: mean, and the LOWER triangle of P mirrored into both triangles (only the lower
-    // triangle of Pk is ever read by Msckf::predict/update: LLT at :412, :447; the rebuild overwrites all)
     for (int e = tid; e < Nq; e += NTHREADS) mu[e] = gmean[e];
     if (tid == 0) {
         int o = 0;
         for (int b = 0; b < nso3; ++b) { roff[b] = o; o += rot_count(L, b); }
         roff[nso3] = o;
         ish[42] = 0;
-    }
-    if (a.do_update || a.emit == 2) {
-        for (int c = wave; c < N; c += NW)
-            for (int r = c + lane; r < N; r += 64) {
-                double v = gP[r + (size_t)c * N];
-                A[r + c * lda] = v;
-                A[c + r * lda] = v;
-                if (r == c) pdiag[r] = v;
-            }
-    } else {
-        for (int e = tid; e < 144; e += NTHREADS) {
-            int r = e % 12, c = e / 12;
-            if (r >= c) { double v = gP[r + (size_t)c * N]; A[r + c * lda] = v; A[c + r * lda] = v; }
-        }
+        ish[43] = 0;
     }
     __syncthreads();
     SLK_STAMP(1);
 
-    // ---- predict: Msckf.hpp:89-189 (state<->clone cross-covariances stay stale: :171-182)
+    // ---- predict: Msckf.hpp:89-189 (state<->clone cross-covariances stay stale: :171-182).
+    // Only the lower triangle of Pk is ever read by Msckf::predict/update (LLT at :412, :447).
     if (a.do_predict || a.emit == 1) {
-        double *Pblk = pool, *Pn = pool + 160, *scr = pool + 320;   // 156 + 144 + (325+300+32+64)
-        for (int e = tid; e < 144; e += NTHREADS) { int r = e % 12, c = e / 12; Pblk[r + c * 13] = A[r + c * lda]; }
-        __syncthreads();
-        int st = predict_phase<NTHREADS, false>(a, bidx, tid, Pblk, mu, Pn, scr, nullptr);
+        double *Lblk = pool, *Pn = pool + 160, *scr = pool + 320;   // 78 + 144 + (325+300+32+64)
+        int st = predict_phase<NTHREADS, false>(a, bidx, tid, [&](int i, int j) { return gP[i + (size_t)j * N]; },
+                                                Lblk, mu, Pn, scr, nullptr);
         if (a.emit == 1) return;
         status |= st;
         if (!(st & SLK_ST_LLT_FAIL)) {                // else: predict skipped, filter unchanged
             for (int e = tid; e < 144; e += NTHREADS) {
                 int r = e % 12, c = e / 12;
                 gP[r + (size_t)c * N] = Pn[e];
-                double v = (r >= c) ? Pn[e] : Pn[c + 12 * r];    // on chip: lower triangle mirrored
-                A[r + c * lda] = v;
-                if (r == c) pdiag[r] = v;
+                pn12[e] = (r >= c) ? Pn[e] : Pn[c + 12 * r];     // on chip: lower triangle mirrored
             }
             for (int e = tid; e < 13; e += NTHREADS) gmean[e] = mu[e];
+            if (tid == 0) ish[43] = 1;
         }
         __syncthreads();
     }
+    const bool predicted = ish[43] != 0;
+    // lower-triangle element of the (predicted) covariance: the fresh 12x12 block comes from LDS
+    auto Pin = [&](int i, int j) -> double {
+        return (predicted && i < 12) ? pn12[i + 12 * j] : gP[i + (size_t)j * N];
+    };
 
     SLK_STAMP(2);
     if (a.do_update || a.emit == 2) {
         // ---- sigma points of the full state: Msckf.hpp:228-229 -> :400-431
-        int fail = chol_lower_regs<NTHREADS, SDN>(A, N, lda, colbuf, tid, [&](int i, int j) { return A[i + j * lda]; });
+        int fail = chol_packed<NTHREADS, SDN>(Lp, N, colbuf, tid, Pin);
         SLK_STAMP(3);
         if (fail >= 0) {
             status |= SLK_ST_LLT_FAIL;
@@ -594,11 +617,11 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
             for (int e = tid; e < S * N; e += NTHREADS) {
                 int t = e % N, i = e / N, blk = 0, comp = 0;
                 int s = t2s(L, t, blk, comp);
-                if (s >= 0) X[(size_t)i * Nq + s] = mu[s] + pert(A, lda, nullptr, t, sig_of(i));
+                if (s >= 0) X[(size_t)i * Nq + s] = mu[s] + pert(Lp, N, nullptr, t, sig_of(i));
             }
             for (int e = tid; e < S * nso3; e += NTHREADS) {
                 int b = e % nso3, i = e / nso3;
-                Quat q = sigma_quat(L, mu, A, lda, nullptr, b, sig_of(i));
+                Quat q = sigma_quat(L, mu, Lp, nullptr, b, sig_of(i));
                 double *o = X + (size_t)i * Nq + so3_soff(L, b);
                 o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
             }
@@ -609,11 +632,11 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
             double *Pxz = DZ + round_up(N * m, 2);              // N x m (ld N)
             double *K = Pxz + round_up(N * m, 2);               // N x m' (ld N)
             double *Sm = K + round_up(N * m, 2);                // m x m (ld m)
-            double *G = Sm + round_up(m * m, 2);                // m' x m' factor of S (ld m'+1) / Gauss-Jordan tableau
+            double *G = Sm + round_up(m * m, 2);                // packed factor of S / Gauss-Jordan tableau
             double *zbar = G + round_up(m * (2 * m + 1), 2);
             double *innov = zbar + round_up(m, 2);
             int *idx = ish;
-            measurement_moments<NTHREADS>(a, L, bidx, tid, mu, A, lda, Z, DZ, Pxz, Sm, zbar, innov, &ish[42]);
+            measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lp, Z, DZ, Pxz, Sm, zbar, innov, &ish[42]);
             SLK_STAMP(6);
             // removeOutliers (:241 -> :723-754) incl. the shifted second erase (:741-744)
             if (tid == 0) {
@@ -651,26 +674,53 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
                 // K = covXZ * S^-1 (:257).  S = 1/2 dZ dZ^T + R is symmetric positive definite for any
                 // valid R: factor it (S = Ls Ls^T) and solve row-wise; a non-SPD S falls back to
                 // Gauss-Jordan with partial pivoting (the reference inverts with PartialPivLU).
-                const int ldg = mmr + 1;
-                int sfail = chol_lower_regs<NTHREADS, SDM>(G, mmr, ldg, colbuf, tid,
-                                                           [&](int i, int j) { return Sm[idx[i] + m * idx[j]]; });
+                int sfail = chol_packed<NTHREADS, SDM>(G, mmr, colbuf, tid,
+                                                       [&](int i, int j) { return Sm[idx[i] + m * idx[j]]; });
                 bool singular = false;
-                if (sfail < 0) {
+                if (sfail < 0 && mmr <= 8) {
+                    // row-wise solve held in registers (fully unrolled for m' <= 8)
+                    double ginv[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) ginv[c] = (c < mmr) ? 1.0 / G[pk(mmr, c, c)] : 0.0;
+                    for (int t = tid; t < N; t += NTHREADS) {
+                        double x[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {                 // forward: Ls w = p
+                            x[c] = 0.0;
+                            if (c < mmr) {
+                                double sum = Pxz[t + N * idx[c]];
+#pragma unroll
+                                for (int p = 0; p < c; ++p) sum -= G[pk(mmr, c, p)] * x[p];
+                                x[c] = sum * ginv[c];
+                            }
+                        }
+#pragma unroll
+                        for (int c = 7; c >= 0; --c) {                // backward: Ls^T x = w
+                            if (c < mmr) {
+                                double sum = x[c];
+#pragma unroll
+                                for (int p = c + 1; p < 8; ++p)
+                                    if (p < mmr) sum -= G[pk(mmr, p, c)] * x[p];
+                                x[c] = sum * ginv[c];
+                                K[t + N * c] = x[c];
+                            }
+                        }
+                    }
+                } else if (sfail < 0) {
                     for (int t = tid; t < N; t += NTHREADS) {
                         for (int c = 0; c < mmr; ++c) {               // forward: Ls w = p
                             double sum = Pxz[t + N * idx[c]];
-                            for (int p = 0; p < c; ++p) sum -= G[c + p * ldg] * K[t + N * p];
-                            K[t + N * c] = sum / G[c + c * ldg];
+                            for (int p = 0; p < c; ++p) sum -= G[pk(mmr, c, p)] * K[t + N * p];
+                            K[t + N * c] = sum / G[pk(mmr, c, c)];
                         }
                         for (int c = mmr - 1; c >= 0; --c) {          // backward: Ls^T x = w
                             double sum = K[t + N * c];
-                            for (int p = c + 1; p < mmr; ++p) sum -= G[p + c * ldg] * K[t + N * p];
-                            K[t + N * c] = sum / G[c + c * ldg];
+                            for (int p = c + 1; p < mmr; ++p) sum -= G[pk(mmr, p, c)] * K[t + N * p];
+                            K[t + N * c] = sum / G[pk(mmr, c, c)];
                         }
                     }
                 } else {
                     const int ldj = 2 * mmr + 1;
-                    __syncthreads();
                     for (int e = tid; e < mmr * mmr; e += NTHREADS) {
                         int r = e % mmr, c = e / mmr;
                         G[r * ldj + c] = Sm[idx[r] + m * idx[c]];
@@ -724,10 +774,9 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
                     SLK_STAMP(9);
                     SLK_STAMP(10);
                     // ---- Pk -= K S K^T (:262) fused into the load of applyDelta's Cholesky (:263 -> :659-662):
-                    // K S = covXZ, so the downdated lower triangle is P(i,j) - sum_c covXZ(i,c) K(j,c);
-                    // P itself still sits in the strict upper triangle of A and in pdiag.
-                    fail = chol_lower_regs<NTHREADS, SDN>(A, N, lda, colbuf, tid, [&](int i, int j) {
-                        double p = (i == j) ? pdiag[i] : A[j + i * lda];
+                    // K S = covXZ, so the downdated lower triangle is P(i,j) - sum_c covXZ(i,c) K(j,c).
+                    fail = chol_packed<NTHREADS, SDN>(Lp, N, colbuf, tid, [&](int i, int j) {
+                        double p = Pin(i, j);
                         double sum = 0.0;
                         for (int c = 0; c < mmr; ++c) sum += Pxz[i + N * idx[c]] * K[j + N * c];
                         return p - sum;
@@ -737,33 +786,32 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
                         status |= SLK_ST_LLT_FAIL;
                     } else {
                         // ---- re-drawn sigma points, manifold mean (:664 -> :499-525), covariance (:665)
-                        double *DR = pool;                                // rotation deviations, 3 per stored item
-                        double *Dp = pool + round_up(3 * cv.W, 2);        // [2][KP][LDD] panels
                         const int W = cv.W;
+                        double *d0 = pool;                                // [nso3][3]: rotation deviation of X_0's blocks
+                        double *DR = pool + round_up(3 * nso3, 2);        // mean loop: 3 per rotation item
+                        double *Dp = DR;                                  // rebuild: [2][KP][LDD] panels (aliases DR)
                         // reference = X[0] = mu + delta (:501)
                         for (int t = tid; t < N; t += NTHREADS) {
                             int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
                             if (s >= 0) ref[s] = mu[s] + delta[t];
                         }
                         for (int b = tid; b < nso3; b += NTHREADS)
-                            stq(ref + so3_soff(L, b), sigma_quat(L, mu, A, lda, delta, b, sig_of(0)));
+                            stq(ref + so3_soff(L, b), sigma_quat(L, mu, Lp, delta, b, sig_of(0)));
                         __syncthreads();
                         int it = 0;
                         double norm = 0.0;
-                        bool final_pass = false;
-                        for (;;) {                                        // :507-516, then one pass against the final mean
+                        do {                                              // :507-516
                             // rotation blocks of X_i [-] ref, only the sigma points whose block differs from X_0's
                             for (int w = tid; w < W; w += NTHREADS) {
                                 int b = 0;
-                                while (w >= roff[b + 1]) ++b;
+                                for (int c = 1; c < nso3; ++c) b += (w >= roff[c]) ? 1 : 0;
                                 int i = w - roff[b];
-                                Quat q = sigma_quat(L, mu, A, lda, delta, b, sig_of(i));
+                                Quat q = sigma_quat(L, mu, Lp, delta, b, sig_of(i));
                                 double dx, dy, dz;
                                 so3_boxminus(q, ldq(ref + so3_soff(L, b)), dx, dy, dz);
                                 DR[3 * w] = dx; DR[3 * w + 1] = dy; DR[3 * w + 2] = dz;
                             }
                             __syncthreads();
-                            if (final_pass) break;
                             // mean_delta = sum_i (X_i [-] ref) / S, 4 lanes per tangent row
                             for (int t = tid / 4; t < N; t += NTHREADS / 4) {
                                 int blk = 0, comp = 0, s = t2s(L, t, blk, comp), sub = tid & 3;
@@ -771,7 +819,7 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
                                 if (s >= 0) {
                                     double m0 = mu[s], r0 = ref[s], dl = delta[t];
                                     sum = group_sum<4>(sub, t + 1, [&](int j) {
-                                        double l = A[t + j * lda];
+                                        double l = Lp[pk(N, t, j)];
                                         return ((m0 + (dl + l)) - r0) + ((m0 + (dl - l)) - r0);
                                     });
                                     sum += (double)(S - 2 * (t + 1)) * ((m0 + dl) - r0);
@@ -796,33 +844,42 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
                                 stq(ref + so, qmul(ldq(ref + so), so3_exp(md[to], md[to + 1], md[to + 2])));
                             }
                             __syncthreads();
-                            if (!(norm > 1e-6 && ++it < 10000)) final_pass = true;
-                        }
+                        } while (norm > 1e-6 && ++it < 10000);
                         if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
                         SLK_STAMP(12);
                         SLK_NOTE(20, it + 1);
+                        // deviation of X_0's rotation blocks from the final mean: shared by every sigma point
+                        // whose block was not perturbed (columns j > toff_b + 2 of a lower-triangular factor)
+                        for (int b = tid; b < nso3; b += NTHREADS) {
+                            Quat q = sigma_quat(L, mu, Lp, delta, b, sig_of(0));
+                            so3_boxminus(q, ldq(ref + so3_soff(L, b)), d0[3 * b], d0[3 * b + 1], d0[3 * b + 2]);
+                        }
+                        // mean written out now: `ref` is final
+                        for (int e = tid; e < Nq; e += NTHREADS) gmean[e] = ref[e];
+                        __syncthreads();
                         SLK_STAMP(13);
-                        // ---- P+ = 1/2 D D^T on the fp64 matrix cores, D generated panel by panel
+                        // ---- P+ = 1/2 D D^T on the fp64 matrix cores (:665 -> :574-589), D generated panel by
+                        // panel: vector rows straight from the factor, rotation rows log(mu+^-1 * X_i) on the fly
                         constexpr int TN = 16 * NT;
                         constexpr int RPT = (TN + 63) / 64;                 // rows of D handled per lane
                         constexpr int TPW = MfmaTiles<NT, NW, 0>::TPW;
-                        // per-lane constants of its D rows: vector rows read L, rotation rows read DR
-                        int rkind[RPT], roffs[RPT], rcnt[RPT];
+                        int rkind[RPT];
                         double rm[RPT], rd[RPT], rr[RPT];
 #pragma unroll
                         for (int q = 0; q < RPT; ++q) {
                             int t = lane + 64 * q, blk = 0, comp = 0;
-                            rkind[q] = 0; roffs[q] = 0; rcnt[q] = 0; rm[q] = 0.0; rd[q] = 0.0; rr[q] = 0.0;
+                            rkind[q] = 0; rm[q] = 0.0; rd[q] = 0.0; rr[q] = 0.0;
                             if (t < N) {
                                 int s = t2s(L, t, blk, comp);
-                                if (s >= 0) { rkind[q] = 1; roffs[q] = t; rm[q] = mu[s]; rd[q] = delta[t]; rr[q] = ref[s]; }
-                                else { rkind[q] = 2; roffs[q] = 3 * roff[blk] + comp; rcnt[q] = roff[blk + 1] - roff[blk]; }
-                            }
+                                if (s >= 0) { rkind[q] = 1; rm[q] = mu[s]; rd[q] = delta[t]; rr[q] = ref[s]; }
+                                else rkind[q] = 2;
+                            } else if (t >= TN) rkind[q] = 3;
                         }
                         d4 acc[TPW];
 #pragma unroll
                         for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-                        auto gen_panel = [&](int p0, double *Dq) {
+                        auto gen_panel = [&](int p0, double *Dq) __attribute__((always_inline)) {
+                            // vector rows and padding
                             for (int kk = wave; kk < KP; kk += NW) {
                                 int i = p0 + kk;
                                 int j = (i - 1) >> 1;
@@ -830,19 +887,27 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
 #pragma unroll
                                 for (int q = 0; q < RPT; ++q) {
                                     int t = lane + 64 * q;
-                                    if (t < TN) {
-                                        double v = 0.0;
-                                        if (i < S) {
-                                            if (rkind[q] == 1) {
-                                                double l = (i > 0 && j <= t) ? sgn * A[roffs[q] + j * lda] : 0.0;
-                                                v = (rm[q] + (rd[q] + l)) - rr[q];
-                                            } else if (rkind[q] == 2) {
-                                                v = DR[roffs[q] + 3 * (i < rcnt[q] ? i : 0)];
-                                            }
-                                        }
-                                        Dq[kk * LDD + t] = v;
+                                    if (rkind[q] == 1) {
+                                        double l = (i > 0 && i < S && j <= t) ? sgn * Lp[pk(N, t, j)] : 0.0;
+                                        Dq[kk * LDD + t] = (i < S) ? (rm[q] + (rd[q] + l)) - rr[q] : 0.0;
+                                    } else if (rkind[q] == 0) {
+                                        Dq[kk * LDD + t] = 0.0;
                                     }
                                 }
+                            }
+                            // rotation rows: one item per (sigma point of the panel, SO(3) block)
+                            for (int e = tid; e < KP * nso3; e += NTHREADS) {
+                                int kk = e % KP, b = e / KP, i = p0 + kk, to = so3_toff(L, b);
+                                double dx = 0.0, dy = 0.0, dz = 0.0;
+                                if (i < S) {
+                                    if (i < roff[b + 1] - roff[b]) {
+                                        Quat q = sigma_quat(L, mu, Lp, delta, b, sig_of(i));
+                                        so3_boxminus(q, ldq(ref + so3_soff(L, b)), dx, dy, dz);
+                                    } else {
+                                        dx = d0[3 * b]; dy = d0[3 * b + 1]; dz = d0[3 * b + 2];
+                                    }
+                                }
+                                Dq[kk * LDD + to] = dx; Dq[kk * LDD + to + 1] = dy; Dq[kk * LDD + to + 2] = dz;
                             }
                         };
                         gen_panel(0, Dp);
@@ -861,11 +926,7 @@ __global__ __launch_bounds__(NTHREADS) void msckf_step_kernel(KArgs a)
                             __syncthreads();
                         }
                         SLK_STAMP(14);
-                        MfmaTiles<NT, NW, 0>::store(A, lda, N, acc, wave, lane);
-                        __syncthreads();
-                        for (int c = wave; c < N; c += NW)
-                            for (int r = lane; r < N; r += 64) gP[r + (size_t)c * N] = A[r + c * lda];
-                        for (int e = tid; e < Nq; e += NTHREADS) gmean[e] = ref[e];
+                        MfmaTiles<NT, NW, 0>::store(gP, N, acc, wave, lane);
                         SLK_STAMP(15);
                     }
                 }

@@ -16,10 +16,10 @@ __host__ __device__ inline UCarve carve_usckf(int N, int Nq, int m, int NT)
     c.S = 2 * N + 1;
     int o = 0;
     c.P = o;      o += round_up(N * c.lda, 2);
-    c.Lm = o;     o += round_up(N * c.lda, 2);
+    c.Lm = o;     o += round_up(pk_size(N), 2);
     c.mu = o;     o += round_up(Nq, 2);
     c.small = o;  o += 64;
-    c.colbuf = o; o += 2 * (16 * NT > 32 ? 16 * NT : 32);
+    c.colbuf = o; o += 4 * (16 * NT > 32 ? 16 * NT : 32);
     c.pool = o;
     int upd = round_up(c.S * m, 2) + 3 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (m + 1), 2)
               + 4 * round_up(m, 2) + round_up(N, 2);
@@ -56,28 +56,27 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
 
     if (a.do_predict || a.emit == 1) {
         // ---- Usckf::predict, Usckf.hpp:107-244
-        double *Pblk = pool, *Pn = pool + 160, *Pxy = pool + 320, *Fk = pool + 480, *scr = pool + 640;
+        double *Lblk = pool, *Pn = pool + 160, *Pxy = pool + 320, *Fk = pool + 480, *scr = pool + 640;
         double *RB = pool + 640 + 800;             // old rows 24..35 of P: 12 x N (ld 12)
         double *CB = RB + round_up(12 * N, 2);     // old cols 24..35 of P: N x 12 (ld N)
-        for (int e = tid; e < 144; e += NTHREADS) { int r = e % 12, c = e / 12; Pblk[r + c * 13] = P[(24 + r) + (24 + c) * lda]; }
-        __syncthreads();
-        int st = predict_phase<NTHREADS, true>(a, bidx, tid, Pblk, mu + 26, Pn, scr, Pxy);
+        int st = predict_phase<NTHREADS, true>(a, bidx, tid, [&](int i, int j) { return P[(24 + i) + (24 + j) * lda]; },
+                                               Lblk, mu + 26, Pn, scr, Pxy);
         if (a.emit == 1) return;
         status |= st;
         if (!(st & SLK_ST_LLT_FAIL)) {
             // Fk = Pxy^T * Pk_i^-1 (:154).  Pk_i = L L^T (its Cholesky factor is in Pblk), so
-            // Fk^T = Pk_i^-1 Pxy: one forward + one backward substitution per column.
+            // Fk^T = Pk_i^-1 Pxy: one forward + one backward substitution per column (Lblk = packed factor).
             if (tid < 12) {
                 double x[12];
                 for (int r = 0; r < 12; ++r) {
                     double s = Pxy[r + 12 * tid];
-                    for (int p = 0; p < r; ++p) s -= Pblk[r + p * 13] * x[p];
-                    x[r] = s / Pblk[r + r * 13];
+                    for (int p = 0; p < r; ++p) s -= Lblk[pk(12, r, p)] * x[p];
+                    x[r] = s / Lblk[pk(12, r, r)];
                 }
                 for (int r = 11; r >= 0; --r) {
                     double s = x[r];
-                    for (int p = r + 1; p < 12; ++p) s -= Pblk[p + r * 13] * x[p];
-                    x[r] = s / Pblk[r + r * 13];
+                    for (int p = r + 1; p < 12; ++p) s -= Lblk[pk(12, p, r)] * x[p];
+                    x[r] = s / Lblk[pk(12, r, r)];
                 }
                 for (int r = 0; r < 12; ++r) Fk[tid + 12 * r] = x[r];      // column tid of Fk^T = row tid of Fk
             }
@@ -122,7 +121,7 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
 
     if (a.do_update || a.emit == 2) {
         // ---- Usckf::update, Usckf.hpp:246-308
-        int fail = chol_lower_regs<NTHREADS, SDN>(Lm, N, lda, colbuf, tid, [&](int i, int j) { return P[i + j * lda]; });
+        int fail = chol_packed<NTHREADS, SDN>(Lm, N, colbuf, tid, [&](int i, int j) { return P[i + j * lda]; });
         bool applied = false;
         if (fail >= 0) {
             status |= SLK_ST_LLT_FAIL;
@@ -131,11 +130,11 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
             for (int e = tid; e < S * N; e += NTHREADS) {
                 int t = e % N, i = e / N, blk = 0, comp = 0;
                 int s = t2s(L, t, blk, comp);
-                if (s >= 0) X[(size_t)i * Nq + s] = mu[s] + pert(Lm, lda, nullptr, t, sig_of(i));
+                if (s >= 0) X[(size_t)i * Nq + s] = mu[s] + pert(Lm, N, nullptr, t, sig_of(i));
             }
             for (int e = tid; e < S * 3; e += NTHREADS) {
                 int b = e % 3, i = e / 3;
-                Quat q = sigma_quat(L, mu, Lm, lda, nullptr, b, sig_of(i));
+                Quat q = sigma_quat(L, mu, Lm, nullptr, b, sig_of(i));
                 double *o = X + (size_t)i * Nq + so3_soff(L, b);
                 o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
             }
@@ -150,31 +149,30 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
             double *innov = zbar + round_up(m, 2);
             double *wv = innov + round_up(m, 2);                 // Ls^-1 innovation
             double *dlt = wv + 2 * round_up(m, 2);
-            measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lm, lda, Z, DZ, Pxz, Sm, zbar, innov, &ish[42]);
+            measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lm, Z, DZ, Pxz, Sm, zbar, innov, &ish[42]);
             // S^-1 (:285-286): S = 1/2 dZ dZ^T + R is SPD for a valid R -> Cholesky, row-wise solves
-            const int ldg = m + 1;
-            int sfail = chol_lower_regs<NTHREADS, SDM>(G, m, ldg, colbuf, tid, [&](int i, int j) { return Sm[i + m * j]; });
+            int sfail = chol_packed<NTHREADS, SDM>(G, m, colbuf, tid, [&](int i, int j) { return Sm[i + m * j]; });
             if (sfail >= 0) {
                 status |= SLK_ST_SINGULAR;
             } else {
                 for (int t = tid; t < N; t += NTHREADS) {             // K = covXZ * S^-1 :288
                     for (int c = 0; c < m; ++c) {
                         double sum = Pxz[t + N * c];
-                        for (int p = 0; p < c; ++p) sum -= G[c + p * ldg] * K[t + N * p];
-                        K[t + N * c] = sum / G[c + c * ldg];
+                        for (int p = 0; p < c; ++p) sum -= G[pk(m, c, p)] * K[t + N * p];
+                        K[t + N * c] = sum / G[pk(m, c, c)];
                     }
                     for (int c = m - 1; c >= 0; --c) {
                         double sum = K[t + N * c];
-                        for (int p = c + 1; p < m; ++p) sum -= G[p + c * ldg] * K[t + N * p];
-                        K[t + N * c] = sum / G[c + c * ldg];
+                        for (int p = c + 1; p < m; ++p) sum -= G[pk(m, p, c)] * K[t + N * p];
+                        K[t + N * c] = sum / G[pk(m, c, c)];
                     }
                 }
                 if (tid == 0) {                                        // mahalanobis2 = |Ls^-1 innovation|^2 :292
                     double d2 = 0.0;
                     for (int c = 0; c < m; ++c) {
                         double sum = innov[c];
-                        for (int p = 0; p < c; ++p) sum -= G[c + p * ldg] * wv[p];
-                        wv[c] = sum / G[c + c * ldg];
+                        for (int p = 0; p < c; ++p) sum -= G[pk(m, c, p)] * wv[p];
+                        wv[c] = sum / G[pk(m, c, c)];
                         d2 += wv[c] * wv[c];
                     }
                     bool ok = true;

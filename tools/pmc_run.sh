@@ -1,0 +1,32 @@
+#!/bin/bash
+# PMC passes for the bench kernel (counters in their own runs, no trace domains mixed in).
+# usage: tools/pmc_run.sh <tag>   (run on the GPU box; writes gpurun_out/pmc_<tag>_*.csv summaries)
+set -e
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+TAG=${1:-x}
+export TMPDIR=/tmp
+OUT=/tmp/pmc_$TAG
+rm -rf $OUT; mkdir -p $OUT gpurun_out
+run() {  # name, counters...
+  name=$1; shift
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/$name.log 2>&1 || { tail -5 $OUT/$name.log; return 1; }
+  f=$(find $OUT/$name -name '*counter_collection.csv' | head -1)
+  python3 - "$f" "$name" <<'PY'
+import csv, sys, collections
+f, name = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for row in csv.DictReader(open(f)):
+    k = row["Kernel_Name"]
+    if "msckf_step" not in k: continue
+    acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); 
+    n[(k, row["Counter_Name"])] += 1
+for k in acc:
+    print(name, k[:60])
+    for c, v in acc[k].items():
+        print(f"   {c:28s} per-dispatch {v / n[(k, c)]:.4g}")
+PY
+}
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU 2>&1 | tee gpurun_out/pmc_${TAG}_sq1.txt
+run sq2 SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM 2>&1 | tee gpurun_out/pmc_${TAG}_sq2.txt
+run tcc1 FETCH_SIZE 2>&1 | tee gpurun_out/pmc_${TAG}_fetch.txt
+run tcc2 WRITE_SIZE 2>&1 | tee gpurun_out/pmc_${TAG}_write.txt
