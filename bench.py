@@ -178,6 +178,15 @@ def main():
         flops = algorithmic_flops(N, m)
         achieved = flops * B / (kernel_ms * 1e-3) / 1e12
         hbm = algorithmic_bytes(N, Nq, m) * B / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        try:    # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                t = json.load(fh)
+            w = t["workload"]
+            if (w["state_dim"], w["meas_rows"], w["batch_per_gpu"]) == (N, m, B):
+                traffic = (2.0 * t["fetch_size_kb_per_launch"] + t["write_size_kb_per_launch"]) * 1024.0
+        except (OSError, KeyError, ValueError):
+            traffic = None
         out = {
             "metric": "filter predict+update steps/sec",
             "value": B * world * args.steps / elapsed,
@@ -196,7 +205,9 @@ def main():
                        "state_dim": N, "meas_rows": m, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": f"independent filters sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/pmc_traffic.json",
+                         "algorithmic_bytes_per_launch": algorithmic_bytes(N, Nq, m) * B,
                          "kernel": "msckf_step_kernel", "kernel_ms": kernel_ms,
                          "flops_per_filter_step": flops,
                          "hbm_algorithmic_GBs": hbm, "hbm_frac": hbm / PEAK_HBM_GBS},

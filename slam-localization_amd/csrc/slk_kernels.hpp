@@ -15,7 +15,7 @@ namespace slk {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int KP = 16;       // sigma points per rebuild panel (4 MFMA k-steps), double-buffered
+constexpr int KP = 8;        // sigma points per rebuild panel (2 MFMA k-steps), double-buffered
 constexpr int MAXM = 32;     // max measurement rows handled on chip
 constexpr int PRED_SCRATCH = 1536;  // doubles of pool used by the 12-DOF predict phase
 
@@ -126,18 +126,16 @@ __host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT)
     c.md = o;     o += round_up(N, 2);
     c.pn12 = o;   o += 144;
     c.small = o;  o += 96;
-    c.colbuf = o; o += 4 * (c.TN > 32 ? c.TN : 32);
+    c.colbuf = o; o += 4 * ((c.TN > 32 ? c.TN : 32) + 2);
     c.pool = o;
     // measurement part: Z[S*m] DZ[N*m] Pxz[N*m] K[N*m] Sm[m*m] G[m*(2m+1)] zbar innov
     int upd1 = round_up(c.S * m, 2) + 3 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (2 * m + 1), 2)
                + 4 * round_up(m, 2);
-    // applyDelta part: rotation deviations of the mean loop (3*W), then the double-buffered panels (aliased)
-    int upd2a = round_up(3 * c.W, 2) + round_up(3 * L.nso3, 2);
-    int upd2b = 2 * KP * c.LDD + round_up(3 * L.nso3, 2);
+    // applyDelta part: rotation deviations (3 per item that differs from X_0) + the double-buffered panels
+    int upd2 = round_up(3 * c.W, 2) + 2 * KP * c.LDD;
     int pool = PRED_SCRATCH;
     if (upd1 > pool) pool = upd1;
-    if (upd2a > pool) pool = upd2a;
-    if (upd2b > pool) pool = upd2b;
+    if (upd2 > pool) pool = upd2;
     c.total = o + pool;
     return c;
 }
@@ -273,6 +271,155 @@ __device__ __forceinline__ int chol_packed(double *Lp, int n, double *colbuf, in
     CholCols<NTHREADS, SD, 0>::run(a, Lp, n, colbuf, ti, tj, active, fail);
     __syncthreads();
     return (fail >= n) ? -1 : fail;
+}
+
+// ------------------------------------------------------------------ single-wave blocked Cholesky on the matrix cores
+// The whole lower triangle lives in ONE wave as v_mfma_f64_16x16x4 accumulator tiles (lane l, reg r of
+// tile (I,J): row 16I + (l>>4) + 4r, col 16J + (l&15)).  A step retires FOUR columns: the 16 lanes
+// holding them publish the raw columns to LDS, every lane redoes the 4x4 pivot block itself (four
+// v_rsq_f64 pivots), forward-substitutes the panel rows it needs as its A/B fragment (lane l ->
+// L[16I + (l&15)][k0 + (l>>4)], which is also the element it stores to the packed factor) and the
+// trailing matrix gets acc(I,J) -= L_I L_J^T as one MFMA per tile (rank-4 update).  No workgroup
+// barrier: LDS traffic of one wave is ordered.  15 steps for n = 60 instead of 60 column steps.
+__host__ __device__ constexpr int tile_idx(int I, int J) { return I * (I + 1) / 2 + J; }
+
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int NT> struct CholM {
+    static constexpr int NTL = NT * (NT + 1) / 2;
+    static constexpr int LDC = 16 * NT + 2;
+    static constexpr int COLBUF = 4 * LDC;
+};
+
+template <int NT, class InitFn>
+__device__ __forceinline__ void cholm_load(d4 (&acc)[CholM<NT>::NTL], int n, int lane, InitFn init)
+{
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = 16 * I + g + 4 * r, col = 16 * J + c;
+                double v;
+                if (row < n && col < n) v = (row >= col) ? init(row, col) : init(col, row);
+                else v = (row == col) ? 1.0 : 0.0;
+                acc[tile_idx(I, J)][r] = v;
+            }
+}
+
+// acc -= X * Y^T with X, Y n x kk column-major panels in LDS (ld ldx / ldy); column c of X is xcol(c)
+template <int NT, class XFn, class YFn>
+__device__ __forceinline__ void cholm_downdate(d4 (&acc)[CholM<NT>::NTL], int n, int kk, int lane, XFn xel, YFn yel)
+{
+    const int c = lane & 15, g = lane >> 4;
+    for (int ks = 0; ks * 4 < kk; ++ks) {
+        const int cc = 4 * ks + g;
+        double af[NT], bf[NT];
+#pragma unroll
+        for (int I = 0; I < NT; ++I) {
+            int rho = 16 * I + c;
+            bool ok = cc < kk && rho < n;
+            af[I] = ok ? -xel(rho, cc) : 0.0;
+            bf[I] = ok ? yel(rho, cc) : 0.0;
+        }
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J)
+                acc[tile_idx(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[I], bf[J], acc[tile_idx(I, J)], 0, 0, 0);
+    }
+}
+
+template <int NT, int JK>
+struct CholMCols {
+    __device__ __forceinline__ static void run(d4 (&acc)[CholM<NT>::NTL], double *Lp, int n, double *colbuf, int lane, int &fail)
+    {
+        if constexpr (JK < NT) {
+            constexpr int LDC = CholM<NT>::LDC;
+            const int c = lane & 15, g = lane >> 4;
+            if (fail < 0) {
+                for (int c0 = 0; c0 < 16; c0 += 4) {
+                    const int k0 = 16 * JK + c0;
+                    if (k0 >= n) break;
+                    // 1. publish the four pivot columns, raw
+                    if (c >= c0 && c < c0 + 4) {
+                        double *dst = colbuf + (c - c0) * LDC + g;
+#pragma unroll
+                        for (int I = JK; I < NT; ++I)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dst[16 * I + 4 * r] = acc[tile_idx(I, JK)][r];
+                    }
+                    wave_sync();
+                    // 2. 4x4 pivot block (same values in every lane) and this lane's raw panel rows
+                    const double *pb = colbuf + k0;
+                    const double p00 = pb[0], p10 = pb[1], p20 = pb[2], p30 = pb[3];
+                    const double p11 = pb[LDC + 1], p21 = pb[LDC + 2], p31 = pb[LDC + 3];
+                    const double p22 = pb[2 * LDC + 2], p32 = pb[2 * LDC + 3], p33 = pb[3 * LDC + 3];
+                    double v[NT][4];
+#pragma unroll
+                    for (int I = JK; I < NT; ++I)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) v[I][b] = colbuf[b * LDC + 16 * I + c];
+                    wave_sync();       // the next step's publish must not overtake these reads
+                    double s0, r0, s1, r1, s2, r2, s3, r3;
+                    if (!(p00 > 0.0)) { fail = k0; break; }
+                    rsqrt_pivot(p00, s0, r0);
+                    const double l10 = p10 * r0, l20 = p20 * r0, l30 = p30 * r0;
+                    const double d1 = fma(-l10, l10, p11);
+                    if (!(d1 > 0.0)) { fail = k0 + 1; break; }
+                    rsqrt_pivot(d1, s1, r1);
+                    const double l21 = fma(-l20, l10, p21) * r1, l31 = fma(-l30, l10, p31) * r1;
+                    const double d2 = fma(-l21, l21, fma(-l20, l20, p22));
+                    if (!(d2 > 0.0)) { fail = k0 + 2; break; }
+                    rsqrt_pivot(d2, s2, r2);
+                    const double l32 = fma(-l31, l21, fma(-l30, l20, p32)) * r2;
+                    const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, p33)));
+                    if (!(d3 > 0.0)) { fail = k0 + 3; break; }
+                    rsqrt_pivot(d3, s3, r3);
+                    // 3. forward substitution of the panel rows -> fragments = factor entries
+                    const int kap = k0 + g;
+                    const double sg = (g == 0) ? s0 : (g == 1) ? s1 : (g == 2) ? s2 : s3;
+                    double frag[NT], nfrag[NT];
+#pragma unroll
+                    for (int I = JK; I < NT; ++I) {
+                        const double x0 = v[I][0] * r0;
+                        const double x1 = fma(-x0, l10, v[I][1]) * r1;
+                        const double x2 = fma(-x1, l21, fma(-x0, l20, v[I][2])) * r2;
+                        const double x3 = fma(-x2, l32, fma(-x1, l31, fma(-x0, l30, v[I][3]))) * r3;
+                        double f = (g == 0) ? x0 : (g == 1) ? x1 : (g == 2) ? x2 : x3;
+                        const int rho = 16 * I + c;
+                        if (rho == kap) f = sg;
+                        if (rho < kap) f = 0.0;           // strictly upper part of the pivot block / retired rows
+                        frag[I] = f;
+                        nfrag[I] = -f;
+                        if (rho >= kap && rho < n && kap < n) Lp[pk(n, rho, kap)] = f;
+                    }
+                    // 4. rank-4 update of the trailing tiles
+#pragma unroll
+                    for (int I = JK; I < NT; ++I)
+#pragma unroll
+                        for (int J = JK; J <= I; ++J)
+                            acc[tile_idx(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(nfrag[I], frag[J], acc[tile_idx(I, J)], 0, 0, 0);
+                }
+            }
+            CholMCols<NT, JK + 1>::run(acc, Lp, n, colbuf, lane, fail);
+        }
+    }
+};
+
+// factor the matrix held in `acc` (see cholm_load); wave-local, returns -1 or the failing pivot
+template <int NT>
+__device__ __forceinline__ int cholm_factor(d4 (&acc)[CholM<NT>::NTL], double *Lp, int n, double *colbuf, int lane)
+{
+    int fail = -1;
+    // this wave runs a long dependent chain while the co-resident waves do throughput work: let it win issue
+    __builtin_amdgcn_s_setprio(3);
+    CholMCols<NT, 0>::run(acc, Lp, n, colbuf, lane, fail);
+    wave_sync();
+    __builtin_amdgcn_s_setprio(0);
+    return fail;
 }
 
 // ------------------------------------------------------------------ small reductions
@@ -419,15 +566,19 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
 // manifold mean, new Pk_i = cov + Q.  pin(i, j) = lower triangle of the 12x12 covariance block;
 // Lblk (packed, 78) receives its Cholesky factor (Usckf needs it for Fk); x13 = current State mean,
 // replaced by the new mean.  Pn (12x12, ld 12) receives the new block.  Returns 0 or status bits
-// (uniform), -1 after a sigma-point emission.
-// scratch (doubles): Ys[25*13] dbuf[25*12] refs[16] mdel[16] colbuf[128]
-template <int NTHREADS, bool WANT_PXY, class PinFn>
+// (uniform), -1 after a sigma-point emission.  Runs in ONE wave (tid = lane < 64), no workgroup barrier.
+// scratch (doubles): Ys[25*13] dbuf[25*12] refs[16] mdel[16] colbuf[CholM<1>::COLBUF = 72]
+template <bool WANT_PXY, class PinFn>
 __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, PinFn pin, double *Lblk, double *x13,
                                              double *Pn, double *scr, double *Pxy /* 12x12 ld 12, only if WANT_PXY */)
 {
     double *Ys = scr, *dbuf = scr + 25 * 13, *refs = dbuf + 25 * 12, *mdel = refs + 16, *cb = mdel + 16;
-    constexpr int SD12 = (12 + Grid<NTHREADS>::GD - 1) / Grid<NTHREADS>::GD;
-    int fail = chol_packed<NTHREADS, SD12>(Lblk, 12, cb, tid, pin);
+    int fail;
+    {
+        d4 acc[1];
+        cholm_load<1>(acc, 12, tid, pin);
+        fail = cholm_factor<1>(acc, Lblk, 12, cb, tid);
+    }
     if (fail >= 0) return SLK_ST_LLT_FAIL;
     const double *u = a.u ? a.u + (size_t)bidx * a.u_stride : nullptr;
     if (tid < 25) {
@@ -446,20 +597,20 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
             for (int c = 0; c < 13; ++c) Ys[tid * 13 + c] = y[c];
     }
     if (a.emit == 1) return -1;   // sigma points emitted, nothing else to do
-    __syncthreads();
+    wave_sync();
     if (tid < 13) refs[tid] = Ys[tid];              // reference = X[0]  (Msckf.hpp:473)
-    __syncthreads();
+    wave_sync();
     int it = 0, status = 0;
     double norm;
     do {                                            // Msckf.hpp:478-487
         if (tid < 25) state_boxminus(Ys + tid * 13, refs, dbuf + tid * 12);
-        __syncthreads();
+        wave_sync();
         if (tid < 12) {
             double sum = 0.0;
             for (int i = 0; i < 25; ++i) sum += dbuf[i * 12 + tid];
             mdel[tid] = sum / 25.0;
         }
-        __syncthreads();
+        wave_sync();
         double n2 = 0.0;
         for (int t = 0; t < 12; ++t) n2 += mdel[t] * mdel[t];
         norm = sqrt(n2);
@@ -468,14 +619,14 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
             state_boxplus(refs, mdel, nr);
             for (int c = 0; c < 13; ++c) refs[c] = nr[c];
         }
-        __syncthreads();
+        wave_sync();
     } while (norm > 1e-6 && ++it < 10000);
     if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
     // covariance (Msckf.hpp:554-570) + Q (:162)
     if (tid < 25) state_boxminus(Ys + tid * 13, refs, dbuf + tid * 12);
-    __syncthreads();
+    wave_sync();
     const double *Q = a.Q + (size_t)bidx * a.q_stride;
-    for (int e = tid; e < 144; e += NTHREADS) {
+    for (int e = tid; e < 144; e += 64) {
         int r = e % 12, c = e / 12;
         double sum = 0.0;
         for (int i = 0; i < 25; ++i) sum += dbuf[i * 12 + r] * dbuf[i * 12 + c];
@@ -491,9 +642,9 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
             Pxy[e] = 0.5 * sx;
         }
     }
-    __syncthreads();
+    wave_sync();
     if (tid < 13) x13[tid] = refs[tid];
-    __syncthreads();
+    wave_sync();
     return status;
 }
 
@@ -583,9 +734,16 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
     // ---- predict: Msckf.hpp:89-189 (state<->clone cross-covariances stay stale: :171-182).
     // Only the lower triangle of Pk is ever read by Msckf::predict/update (LLT at :412, :447).
     if (a.do_predict || a.emit == 1) {
-        double *Lblk = pool, *Pn = pool + 160, *scr = pool + 320;   // 78 + 144 + (325+300+32+64)
-        int st = predict_phase<NTHREADS, false>(a, bidx, tid, [&](int i, int j) { return gP[i + (size_t)j * N]; },
-                                                Lblk, mu, Pn, scr, nullptr);
+        double *Lblk = pool, *Pn = pool + 160, *scr = pool + 320;   // 78 + 144 + (325+300+32+72)
+        if (wave == 0) {
+            __builtin_amdgcn_s_setprio(3);
+            int st0 = predict_phase<false>(a, bidx, tid, [&](int i, int j) { return gP[i + (size_t)j * N]; },
+                                           Lblk, mu, Pn, scr, nullptr);
+            __builtin_amdgcn_s_setprio(0);
+            if (tid == 0) ish[44] = st0;
+        }
+        __syncthreads();
+        const int st = ish[44];
         if (a.emit == 1) return;
         status |= st;
         if (!(st & SLK_ST_LLT_FAIL)) {                // else: predict skipped, filter unchanged
@@ -608,7 +766,19 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
     SLK_STAMP(2);
     if (a.do_update || a.emit == 2) {
         // ---- sigma points of the full state: Msckf.hpp:228-229 -> :400-431
-        int fail = chol_packed<NTHREADS, SDN>(Lp, N, colbuf, tid, Pin);
+        int fail;
+        if constexpr (NT <= 4) {
+            if (wave == 0) {
+                d4 acc[CholM<NT>::NTL];
+                cholm_load<NT>(acc, N, lane, Pin);
+                int f0 = cholm_factor<NT>(acc, Lp, N, colbuf, lane);
+                if (lane == 0) ish[45] = f0;
+            }
+            __syncthreads();
+            fail = ish[45];
+        } else {
+            fail = chol_packed<NTHREADS, SDN>(Lp, N, colbuf, tid, Pin);
+        }
         SLK_STAMP(3);
         if (fail >= 0) {
             status |= SLK_ST_LLT_FAIL;
@@ -674,8 +844,22 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
                 // K = covXZ * S^-1 (:257).  S = 1/2 dZ dZ^T + R is symmetric positive definite for any
                 // valid R: factor it (S = Ls Ls^T) and solve row-wise; a non-SPD S falls back to
                 // Gauss-Jordan with partial pivoting (the reference inverts with PartialPivLU).
-                int sfail = chol_packed<NTHREADS, SDM>(G, mmr, colbuf, tid,
-                                                       [&](int i, int j) { return Sm[idx[i] + m * idx[j]]; });
+                if (wave == 0) {
+                    auto sel = [&](int i, int j) { return Sm[idx[i] + m * idx[j]]; };
+                    int f0;
+                    if (mmr <= 16) {
+                        d4 acc[CholM<1>::NTL];
+                        cholm_load<1>(acc, mmr, lane, sel);
+                        f0 = cholm_factor<1>(acc, G, mmr, colbuf, lane);
+                    } else {
+                        d4 acc[CholM<2>::NTL];
+                        cholm_load<2>(acc, mmr, lane, sel);
+                        f0 = cholm_factor<2>(acc, G, mmr, colbuf, lane);
+                    }
+                    if (lane == 0) ish[46] = f0;
+                }
+                __syncthreads();
+                const int sfail = ish[46];
                 bool singular = false;
                 if (sfail < 0 && mmr <= 8) {
                     // row-wise solve held in registers (fully unrolled for m' <= 8)
@@ -775,21 +959,33 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
                     SLK_STAMP(10);
                     // ---- Pk -= K S K^T (:262) fused into the load of applyDelta's Cholesky (:263 -> :659-662):
                     // K S = covXZ, so the downdated lower triangle is P(i,j) - sum_c covXZ(i,c) K(j,c).
-                    fail = chol_packed<NTHREADS, SDN>(Lp, N, colbuf, tid, [&](int i, int j) {
-                        double p = Pin(i, j);
-                        double sum = 0.0;
-                        for (int c = 0; c < mmr; ++c) sum += Pxz[i + N * idx[c]] * K[j + N * c];
-                        return p - sum;
-                    });
+                    if constexpr (NT <= 4) {
+                        if (wave == 0) {
+                            d4 acc[CholM<NT>::NTL];
+                            cholm_load<NT>(acc, N, lane, Pin);
+                            cholm_downdate<NT>(acc, N, mmr, lane, [&](int r, int c) { return Pxz[r + N * idx[c]]; },
+                                               [&](int r, int c) { return K[r + N * c]; });
+                            int f0 = cholm_factor<NT>(acc, Lp, N, colbuf, lane);
+                            if (lane == 0) ish[45] = f0;
+                        }
+                        __syncthreads();
+                        fail = ish[45];
+                    } else {
+                        fail = chol_packed<NTHREADS, SDN>(Lp, N, colbuf, tid, [&](int i, int j) {
+                            double p = Pin(i, j);
+                            double sum = 0.0;
+                            for (int c = 0; c < mmr; ++c) sum += Pxz[i + N * idx[c]] * K[j + N * c];
+                            return p - sum;
+                        });
+                    }
                     SLK_STAMP(11);
                     if (fail >= 0) {
                         status |= SLK_ST_LLT_FAIL;
                     } else {
                         // ---- re-drawn sigma points, manifold mean (:664 -> :499-525), covariance (:665)
                         const int W = cv.W;
-                        double *d0 = pool;                                // [nso3][3]: rotation deviation of X_0's blocks
-                        double *DR = pool + round_up(3 * nso3, 2);        // mean loop: 3 per rotation item
-                        double *Dp = DR;                                  // rebuild: [2][KP][LDD] panels (aliases DR)
+                        double *DR = pool;                                // rotation deviations, 3 per stored item
+                        double *Dp = pool + round_up(3 * W, 2);           // [2][KP][LDD] panels
                         // reference = X[0] = mu + delta (:501)
                         for (int t = tid; t < N; t += NTHREADS) {
                             int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
@@ -800,7 +996,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
                         __syncthreads();
                         int it = 0;
                         double norm = 0.0;
-                        do {                                              // :507-516
+                        bool final_pass = false;
+                        for (;;) {                                        // :507-516, then one pass against the final mean (:584)
                             // rotation blocks of X_i [-] ref, only the sigma points whose block differs from X_0's
                             for (int w = tid; w < W; w += NTHREADS) {
                                 int b = 0;
@@ -812,6 +1009,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
                                 DR[3 * w] = dx; DR[3 * w + 1] = dy; DR[3 * w + 2] = dz;
                             }
                             __syncthreads();
+                            if (final_pass) break;
                             // mean_delta = sum_i (X_i [-] ref) / S, 4 lanes per tangent row
                             for (int t = tid / 4; t < N; t += NTHREADS / 4) {
                                 int blk = 0, comp = 0, s = t2s(L, t, blk, comp), sub = tid & 3;
@@ -844,42 +1042,35 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
                                 stq(ref + so, qmul(ldq(ref + so), so3_exp(md[to], md[to + 1], md[to + 2])));
                             }
                             __syncthreads();
-                        } while (norm > 1e-6 && ++it < 10000);
+                            if (!(norm > 1e-6 && ++it < 10000)) final_pass = true;
+                        }
                         if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
                         SLK_STAMP(12);
                         SLK_NOTE(20, it + 1);
-                        // deviation of X_0's rotation blocks from the final mean: shared by every sigma point
-                        // whose block was not perturbed (columns j > toff_b + 2 of a lower-triangular factor)
-                        for (int b = tid; b < nso3; b += NTHREADS) {
-                            Quat q = sigma_quat(L, mu, Lp, delta, b, sig_of(0));
-                            so3_boxminus(q, ldq(ref + so3_soff(L, b)), d0[3 * b], d0[3 * b + 1], d0[3 * b + 2]);
-                        }
                         // mean written out now: `ref` is final
                         for (int e = tid; e < Nq; e += NTHREADS) gmean[e] = ref[e];
-                        __syncthreads();
                         SLK_STAMP(13);
                         // ---- P+ = 1/2 D D^T on the fp64 matrix cores (:665 -> :574-589), D generated panel by
-                        // panel: vector rows straight from the factor, rotation rows log(mu+^-1 * X_i) on the fly
+                        // panel: vector rows straight from the factor, rotation rows from DR
                         constexpr int TN = 16 * NT;
                         constexpr int RPT = (TN + 63) / 64;                 // rows of D handled per lane
                         constexpr int TPW = MfmaTiles<NT, NW, 0>::TPW;
-                        int rkind[RPT];
+                        int rkind[RPT], roffs[RPT], rcnt[RPT];
                         double rm[RPT], rd[RPT], rr[RPT];
 #pragma unroll
                         for (int q = 0; q < RPT; ++q) {
                             int t = lane + 64 * q, blk = 0, comp = 0;
-                            rkind[q] = 0; rm[q] = 0.0; rd[q] = 0.0; rr[q] = 0.0;
+                            rkind[q] = 0; roffs[q] = 0; rcnt[q] = 0; rm[q] = 0.0; rd[q] = 0.0; rr[q] = 0.0;
                             if (t < N) {
                                 int s = t2s(L, t, blk, comp);
                                 if (s >= 0) { rkind[q] = 1; rm[q] = mu[s]; rd[q] = delta[t]; rr[q] = ref[s]; }
-                                else rkind[q] = 2;
+                                else { rkind[q] = 2; roffs[q] = 3 * roff[blk] + comp; rcnt[q] = roff[blk + 1] - roff[blk]; }
                             } else if (t >= TN) rkind[q] = 3;
                         }
                         d4 acc[TPW];
 #pragma unroll
                         for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
                         auto gen_panel = [&](int p0, double *Dq) __attribute__((always_inline)) {
-                            // vector rows and padding
                             for (int kk = wave; kk < KP; kk += NW) {
                                 int i = p0 + kk;
                                 int j = (i - 1) >> 1;
@@ -887,27 +1078,17 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
 #pragma unroll
                                 for (int q = 0; q < RPT; ++q) {
                                     int t = lane + 64 * q;
-                                    if (rkind[q] == 1) {
-                                        double l = (i > 0 && i < S && j <= t) ? sgn * Lp[pk(N, t, j)] : 0.0;
-                                        Dq[kk * LDD + t] = (i < S) ? (rm[q] + (rd[q] + l)) - rr[q] : 0.0;
-                                    } else if (rkind[q] == 0) {
-                                        Dq[kk * LDD + t] = 0.0;
+                                    double v = 0.0;
+                                    if (i < S) {
+                                        if (rkind[q] == 1) {
+                                            double l = (i > 0 && j <= t) ? sgn * Lp[pk(N, t, j)] : 0.0;
+                                            v = (rm[q] + (rd[q] + l)) - rr[q];
+                                        } else if (rkind[q] == 2) {
+                                            v = DR[roffs[q] + 3 * (i < rcnt[q] ? i : 0)];
+                                        }
                                     }
+                                    if (rkind[q] != 3) Dq[kk * LDD + t] = v;
                                 }
-                            }
-                            // rotation rows: one item per (sigma point of the panel, SO(3) block)
-                            for (int e = tid; e < KP * nso3; e += NTHREADS) {
-                                int kk = e % KP, b = e / KP, i = p0 + kk, to = so3_toff(L, b);
-                                double dx = 0.0, dy = 0.0, dz = 0.0;
-                                if (i < S) {
-                                    if (i < roff[b + 1] - roff[b]) {
-                                        Quat q = sigma_quat(L, mu, Lp, delta, b, sig_of(i));
-                                        so3_boxminus(q, ldq(ref + so3_soff(L, b)), dx, dy, dz);
-                                    } else {
-                                        dx = d0[3 * b]; dy = d0[3 * b + 1]; dz = d0[3 * b + 2];
-                                    }
-                                }
-                                Dq[kk * LDD + to] = dx; Dq[kk * LDD + to + 1] = dy; Dq[kk * LDD + to + 2] = dz;
                             }
                         };
                         gen_panel(0, Dp);

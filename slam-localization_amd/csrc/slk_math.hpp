@@ -34,21 +34,42 @@ __device__ __forceinline__ void qrot(const Quat &q, double vx, double vy, double
     oz = vz + q.w * uz + (q.x * uy - q.y * ux);
 }
 
-// MTK cos_sinc_sqrt(x) = (cos(sqrt x), sin(sqrt x)/sqrt x), Taylor series below eps^(1/4) = 2^-13
+// MTK cos_sinc_sqrt(x) = (cos(sqrt x), sin(sqrt x)/sqrt x).  Both are entire functions of x:
+//   cos(sqrt x) = sum (-x)^k/(2k)!,   sin(sqrt x)/sqrt x = sum (-x)^k/(2k+1)!
+// For x < 1/4 (rotation below 1 rad, the usual sigma-point spread) the series are summed directly to
+// below 1 ulp (10 terms, Horner) -- no sqrt, no division, no range reduction; MTK itself switches to
+// this series for tiny x (3 terms below eps^(1/4)).  Larger arguments take the libm route.
 __device__ __forceinline__ void cos_sinc_sqrt(double x, double &c, double &s)
 {
-    if (x >= 1.220703125e-4) {
+    if (x < 0.25) {
+        const double y = -x;                      // Horner in y = -x
+        double cc = 1.0 / 6402373705728000.0;     // 1/18!
+        cc = fma(cc, y, 1.0 / 20922789888000.0);  // 1/16!
+        cc = fma(cc, y, 1.0 / 87178291200.0);     // 1/14!
+        cc = fma(cc, y, 1.0 / 479001600.0);       // 1/12!
+        cc = fma(cc, y, 1.0 / 3628800.0);         // 1/10!
+        cc = fma(cc, y, 1.0 / 40320.0);           // 1/8!
+        cc = fma(cc, y, 1.0 / 720.0);             // 1/6!
+        cc = fma(cc, y, 1.0 / 24.0);              // 1/4!
+        cc = fma(cc, y, 0.5);                     // 1/2!
+        cc = fma(cc, y, 1.0);
+        double ss = 1.0 / 121645100408832000.0;   // 1/19!
+        ss = fma(ss, y, 1.0 / 355687428096000.0); // 1/17!
+        ss = fma(ss, y, 1.0 / 1307674368000.0);   // 1/15!
+        ss = fma(ss, y, 1.0 / 6227020800.0);      // 1/13!
+        ss = fma(ss, y, 1.0 / 39916800.0);        // 1/11!
+        ss = fma(ss, y, 1.0 / 362880.0);          // 1/9!
+        ss = fma(ss, y, 1.0 / 5040.0);            // 1/7!
+        ss = fma(ss, y, 1.0 / 120.0);             // 1/5!
+        ss = fma(ss, y, 1.0 / 6.0);               // 1/3!
+        ss = fma(ss, y, 1.0);
+        c = cc;
+        s = ss;
+    } else {
         double sx = sqrt(x), sn, cs;
         sincos(sx, &sn, &cs);
         c = cs;
         s = sn / sx;
-    } else {
-        double cosi = 1.0, sinc = 1.0, term = -0.5 * x;
-        cosi += term; term *= (1.0 / 3.0); sinc += term; term *= -(1.0 / 4.0) * x;
-        cosi += term; term *= (1.0 / 5.0); sinc += term; term *= -(1.0 / 6.0) * x;
-        cosi += term; term *= (1.0 / 7.0); sinc += term;
-        c = cosi;
-        s = sinc;
     }
 }
 
@@ -60,11 +81,38 @@ __device__ __forceinline__ Quat so3_exp(double vx, double vy, double vz)
     return Quat{m * vx, m * vy, m * vz, c};
 }
 
+// MTK::SO3::log: 2 atan(|vec|/w)/|vec| * vec (|vec| clamped to 1e-11).  With u = |vec|/w the factor is
+// 2/w * atan(u)/u and atan(u)/u = sum (-u^2)^k/(2k+1): for u^2 < 1/16 (rotation below ~28 deg) the
+// series is summed directly (15 terms, < 1 ulp) -- one reciprocal instead of sqrt + 2 divisions + atan.
 __device__ __forceinline__ void so3_log(const Quat &q, double &vx, double &vy, double &vz)
 {
-    double nv = sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
-    if (nv < 1e-11) nv = 1e-11;
-    double s = 2.0 / nv * atan(nv / q.w);
+    const double n2 = q.x * q.x + q.y * q.y + q.z * q.z;
+    const double w2 = q.w * q.w;
+    double s;
+    if (q.w > 0.0 && n2 * 16.0 < w2) {
+        const double rw = 1.0 / q.w;
+        const double y = -(n2 * rw * rw);
+        double f = 1.0 / 29.0;
+        f = fma(f, y, 1.0 / 27.0);
+        f = fma(f, y, 1.0 / 25.0);
+        f = fma(f, y, 1.0 / 23.0);
+        f = fma(f, y, 1.0 / 21.0);
+        f = fma(f, y, 1.0 / 19.0);
+        f = fma(f, y, 1.0 / 17.0);
+        f = fma(f, y, 1.0 / 15.0);
+        f = fma(f, y, 1.0 / 13.0);
+        f = fma(f, y, 1.0 / 11.0);
+        f = fma(f, y, 1.0 / 9.0);
+        f = fma(f, y, 1.0 / 7.0);
+        f = fma(f, y, 1.0 / 5.0);
+        f = fma(f, y, 1.0 / 3.0);
+        f = fma(f, y, 1.0);
+        s = 2.0 * f * rw;
+    } else {
+        double nv = sqrt(n2);
+        if (nv < 1e-11) nv = 1e-11;
+        s = 2.0 / nv * atan(nv / q.w);
+    }
     vx = s * q.x; vy = s * q.y; vz = s * q.z;
 }
 

@@ -19,7 +19,7 @@ __host__ __device__ inline UCarve carve_usckf(int N, int Nq, int m, int NT)
     c.Lm = o;     o += round_up(pk_size(N), 2);
     c.mu = o;     o += round_up(Nq, 2);
     c.small = o;  o += 64;
-    c.colbuf = o; o += 4 * (16 * NT > 32 ? 16 * NT : 32);
+    c.colbuf = o; o += 4 * ((16 * NT > 32 ? 16 * NT : 32) + 2);
     c.pool = o;
     int upd = round_up(c.S * m, 2) + 3 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (m + 1), 2)
               + 4 * round_up(m, 2) + round_up(N, 2);
@@ -59,8 +59,13 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
         double *Lblk = pool, *Pn = pool + 160, *Pxy = pool + 320, *Fk = pool + 480, *scr = pool + 640;
         double *RB = pool + 640 + 800;             // old rows 24..35 of P: 12 x N (ld 12)
         double *CB = RB + round_up(12 * N, 2);     // old cols 24..35 of P: N x 12 (ld N)
-        int st = predict_phase<NTHREADS, true>(a, bidx, tid, [&](int i, int j) { return P[(24 + i) + (24 + j) * lda]; },
-                                               Lblk, mu + 26, Pn, scr, Pxy);
+        if (wave == 0) {
+            int st0 = predict_phase<true>(a, bidx, tid, [&](int i, int j) { return P[(24 + i) + (24 + j) * lda]; },
+                                          Lblk, mu + 26, Pn, scr, Pxy);
+            if (tid == 0) ish[44] = st0;
+        }
+        __syncthreads();
+        const int st = ish[44];
         if (a.emit == 1) return;
         status |= st;
         if (!(st & SLK_ST_LLT_FAIL)) {
@@ -121,7 +126,19 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
 
     if (a.do_update || a.emit == 2) {
         // ---- Usckf::update, Usckf.hpp:246-308
-        int fail = chol_packed<NTHREADS, SDN>(Lm, N, colbuf, tid, [&](int i, int j) { return P[i + j * lda]; });
+        int fail;
+        if constexpr (NT <= 4) {
+            if (wave == 0) {
+                d4 acc[CholM<NT>::NTL];
+                cholm_load<NT>(acc, N, lane, [&](int i, int j) { return P[i + j * lda]; });
+                int f0 = cholm_factor<NT>(acc, Lm, N, colbuf, lane);
+                if (lane == 0) ish[45] = f0;
+            }
+            __syncthreads();
+            fail = ish[45];
+        } else {
+            fail = chol_packed<NTHREADS, SDN>(Lm, N, colbuf, tid, [&](int i, int j) { return P[i + j * lda]; });
+        }
         bool applied = false;
         if (fail >= 0) {
             status |= SLK_ST_LLT_FAIL;
@@ -151,7 +168,22 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
             double *dlt = wv + 2 * round_up(m, 2);
             measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lm, Z, DZ, Pxz, Sm, zbar, innov, &ish[42]);
             // S^-1 (:285-286): S = 1/2 dZ dZ^T + R is SPD for a valid R -> Cholesky, row-wise solves
-            int sfail = chol_packed<NTHREADS, SDM>(G, m, colbuf, tid, [&](int i, int j) { return Sm[i + m * j]; });
+            if (wave == 0) {
+                auto sel = [&](int i, int j) { return Sm[i + m * j]; };
+                int f0;
+                if (m <= 16) {
+                    d4 acc[CholM<1>::NTL];
+                    cholm_load<1>(acc, m, lane, sel);
+                    f0 = cholm_factor<1>(acc, G, m, colbuf, lane);
+                } else {
+                    d4 acc[CholM<2>::NTL];
+                    cholm_load<2>(acc, m, lane, sel);
+                    f0 = cholm_factor<2>(acc, G, m, colbuf, lane);
+                }
+                if (lane == 0) ish[46] = f0;
+            }
+            __syncthreads();
+            const int sfail = ish[46];
             if (sfail >= 0) {
                 status |= SLK_ST_SINGULAR;
             } else {
