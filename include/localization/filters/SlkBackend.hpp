@@ -1,0 +1,80 @@
+/**\file SlkBackend.hpp
+ * Glue between the header facade (Usckf.hpp / Msckf.hpp) and the C ABI (include/slk.h):
+ * RAII handle, registered-model tag types (Tier A) and the host-functor path (Tier B).
+ */
+#ifndef _SLK_BACKEND_HPP_
+#define _SLK_BACKEND_HPP_
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../slk.h"
+#include "State.hpp"
+
+namespace localization
+{
+namespace slk
+{
+    inline void check(int rc, const char *what)
+    {
+        if (rc != SLK_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + slk_last_error());
+    }
+
+    /** Owns one slk_filter (a batch of B filters; B = 1 is the reference object). */
+    class Handle
+    {
+        slk_filter *h_;
+    public:
+        Handle() : h_(0) {}
+        ~Handle() { reset(); }
+        Handle(const Handle &) = delete;
+        Handle &operator=(const Handle &) = delete;
+        void reset() { if (h_) slk_destroy(h_); h_ = 0; }
+        void create(int kind, int batch, int n_clones, int nfk, int nfkl, int device = 0, void *stream = 0)
+        {
+            reset();
+            slk_config cfg = {kind, batch, device, n_clones, nfk, nfkl, stream};
+            check(slk_create(&cfg, &h_), "slk_create");
+        }
+        slk_filter *get() const { return h_; }
+        int N() const { return slk_dof(h_); }
+        int Nq() const { return slk_storage(h_); }
+        int B() const { return slk_batch(h_); }
+    };
+
+    /** Registered process models (run on the GPU).  Any other callable takes the Tier-B path. */
+    struct ConstVelocityModel      /* test/UsckfUnitTest.cpp:34-49 */
+    {
+        double u[7];
+        ConstVelocityModel(const Vec3 &velocity, const Vec3 &angular_velocity, double dt)
+        { for (int i = 0; i < 3; ++i) { u[i] = velocity[i]; u[3 + i] = angular_velocity[i]; } u[6] = dt; }
+    };
+    struct DeltaPoseModel          /* test/MsckfUnitTest.cpp:33-47 */
+    {
+        double u[13];
+        DeltaPoseModel(const Vec3 &dpos, const Quaternion &dq, const Vec3 &velocity, const Vec3 &angular_velocity)
+        {
+            for (int i = 0; i < 3; ++i) { u[i] = dpos[i]; u[7 + i] = velocity[i]; u[10 + i] = angular_velocity[i]; }
+            for (int i = 0; i < 4; ++i) u[3 + i] = dq.coeffs()[i];
+        }
+    };
+    /** Registered measurement models. */
+    struct VoRelativeModel {};     /* test/UsckfUnitTest.cpp:62-86 */
+    struct FeatureProjectionModel  /* m/2 landmarks seen as normalised image points from pose indices */
+    {
+        std::vector<double> params;   /* (x, y, z, pose index) per feature */
+        void add(double x, double y, double z, int pose) { params.push_back(x); params.push_back(y); params.push_back(z); params.push_back(pose); }
+    };
+    struct PosePositionModel { double pose; explicit PosePositionModel(int p) : pose(p) {} };
+
+    template <class T> struct is_registered_process { enum { value = 0 }; };
+    template <> struct is_registered_process<ConstVelocityModel> { enum { value = 1 }; };
+    template <> struct is_registered_process<DeltaPoseModel> { enum { value = 1 }; };
+
+    /** column-major copy of anything with data()/rows()/cols() */
+    template <class M>
+    inline std::vector<double> dense(const M &m) { return std::vector<double>(m.data(), m.data() + (std::size_t)m.rows() * m.cols()); }
+} // namespace slk
+} // namespace localization
+#endif

@@ -64,6 +64,21 @@ def test_product_does_not_import_the_oracle():
     assert "oracle" not in open(os.path.join(ROOT, "include", "slk.h")).read().lower()
 
 
+def test_cpp_header_facade_compiles_and_links(slk):
+    # include/localization/filters/{Usckf,Msckf,State,MtkWrap}.hpp against libslk_hip.so: the reference's
+    # class/enum/method names must be usable the way its unit tests use them (no run here: needs a GPU)
+    import facade_build
+    exe = facade_build.build()
+    assert os.path.exists(exe)
+    hdr = open(os.path.join(ROOT, "include", "localization", "filters", "Usckf.hpp")).read()
+    for name in ("enum CloningMode", "STATEK_I = 3", "class Usckf", "void cloning(int mode)", "setMeasurement(CloningMode mode",
+                 "PkAugmentedState() const", "muSingleState(int state = STATEK_I)"):
+        assert name in hdr, name
+    hdr = open(os.path.join(ROOT, "include", "localization", "filters", "Msckf.hpp")).read()
+    for name in ("class Msckf", "unsigned int update(", "getPkSingleState()", "setPk(", "muState() const"):
+        assert name in hdr, name
+
+
 def test_algorithmic_work_figures_match_survey():
     sys.path.insert(0, ROOT)
     import bench
