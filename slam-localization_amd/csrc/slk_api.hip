@@ -43,6 +43,7 @@ struct slk_filter {
     int *d_status;
     unsigned *d_outliers;
     Stage st_u, st_Q, st_mp, st_z, st_R, st_X, st_Z, st_tmpP, st_tmpM;
+    Stage ws_L, ws_DR;            // large-state workspaces (N > 96), allocated on first use
     hipEvent_t ev0, ev1;
 };
 
@@ -132,7 +133,8 @@ void slk_destroy(slk_filter *f)
     if (!f) return;
     (void)hipSetDevice(f->cfg.device);
     (void)hipStreamSynchronize(f->stream);
-    Stage *st[] = {&f->st_u, &f->st_Q, &f->st_mp, &f->st_z, &f->st_R, &f->st_X, &f->st_Z, &f->st_tmpP, &f->st_tmpM};
+    Stage *st[] = {&f->st_u, &f->st_Q, &f->st_mp, &f->st_z, &f->st_R, &f->st_X, &f->st_Z, &f->st_tmpP, &f->st_tmpM,
+                   &f->ws_L, &f->ws_DR};
     for (Stage *s : st) if (s->p) (void)hipFree(s->p);
     if (f->d_mean) (void)hipFree(f->d_mean);
     if (f->d_P) (void)hipFree(f->d_P);
@@ -178,9 +180,19 @@ int slk_get_state(slk_filter *f, double *mean, double *P, int where)
 
 // ---------------------------------------------------------------------------- launch helpers
 template <int NT, int NTHREADS>
-static int launch_msckf_inst(slk_filter *f, const KArgs &a)
+static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
 {
-    Carve cv = carve_step(a.lay, a.m, NT);
+    KArgs a = a0;
+    constexpr bool BIG = NT > 6;
+    Carve cv = carve_step(a.lay, a.m, NT, BIG);
+    if (BIG) {
+        int rc = stage_reserve(f, f->ws_L, (size_t)a.B * pk_size(a.lay.N));
+        if (rc) return rc;
+        rc = stage_reserve(f, f->ws_DR, (size_t)a.B * 3 * cv.W);
+        if (rc) return rc;
+        a.wsL = f->ws_L.p;
+        a.wsDR = f->ws_DR.p;
+    }
     size_t lds = (size_t)cv.total * sizeof(double);
     if (lds > 160 * 1024) { g_err = "state too large for the LDS-resident kernel"; return SLK_E_UNSUPPORTED; }
     auto kern = msckf_step_kernel<NT, NTHREADS>;
@@ -204,7 +216,10 @@ static int launch_msckf(slk_filter *f, const KArgs &a)
     case 4: return launch_msckf_inst<4, 256>(f, a);
     case 5: return launch_msckf_inst<5, 256>(f, a);
     case 6: return launch_msckf_inst<6, 256>(f, a);
-    default: g_err = "state dimension above 96 is not supported by this build"; return SLK_E_UNSUPPORTED;
+    case 7: case 8: return launch_msckf_inst<8, 256>(f, a);
+    case 9: case 10: return launch_msckf_inst<10, 256>(f, a);
+    case 11: case 12: case 13: return launch_msckf_inst<13, 256>(f, a);
+    default: g_err = "state dimension above 208 is not supported by this build"; return SLK_E_UNSUPPORTED;
     }
 }
 

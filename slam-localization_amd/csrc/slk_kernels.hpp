@@ -32,6 +32,7 @@ struct KArgs {
     const double *R; int r_stride; int gate; const double *Zext;
     // tier B sigma-point emission: 1 = predict sigma points, 2 = update sigma points
     int emit; double *Xout;
+    double *wsL, *wsDR;   // global workspaces of the large-state path (N > 96): packed factor, rotation deviations
     long long *dbg;   // phase stamps, diagnostic builds (-DSLK_STAMPS) only; always null in the product
 };
 
@@ -109,7 +110,9 @@ struct Carve {
     int S, LDD, TN, W;   // W = rotation-row items that differ from X_0 (sum over blocks of rot_count)
 };
 
-__host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT)
+// big = large-state variant (NT > 6): the packed factor and the rotation deviations live in a global
+// workspace, LDS keeps the small vectors, the measurement arrays, a Cholesky panel and the MFMA panels
+__host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT, bool big = false)
 {
     const int N = L.N, Nq = L.Nq;
     Carve c;
@@ -119,23 +122,24 @@ __host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT)
     c.W = 0;
     for (int b = 0; b < L.nso3; ++b) c.W += rot_count(L, b);
     int o = 0;
-    c.Lp = o;     o += round_up(pk_size(N), 2);
+    c.Lp = o;     o += big ? 0 : round_up(pk_size(N), 2);
     c.mu = o;     o += round_up(Nq, 2);
     c.ref = o;    o += round_up(Nq, 2);
     c.delta = o;  o += round_up(N, 2);
     c.md = o;     o += round_up(N, 2);
     c.pn12 = o;   o += 144;
     c.small = o;  o += 96;
-    c.colbuf = o; o += 4 * ((c.TN > 32 ? c.TN : 32) + 2);
+    c.colbuf = o; o += big ? (4 * 34 + 136) : 4 * ((c.TN > 32 ? c.TN : 32) + 2);   // big: cholm<1..2> buffer + packed 16x16 factor
     c.pool = o;
     // measurement part: Z[S*m] DZ[N*m] Pxz[N*m] K[N*m] Sm[m*m] G[m*(2m+1)] zbar innov
     int upd1 = round_up(c.S * m, 2) + 3 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (2 * m + 1), 2)
                + 4 * round_up(m, 2);
     // applyDelta part: rotation deviations (3 per item that differs from X_0) + the double-buffered panels
-    int upd2 = round_up(3 * c.W, 2) + 2 * KP * c.LDD;
+    int upd2 = (big ? 0 : round_up(3 * c.W, 2)) + 2 * KP * c.LDD;
     int pool = PRED_SCRATCH;
     if (upd1 > pool) pool = upd1;
     if (upd2 > pool) pool = upd2;
+    if (big && upd1 + c.TN * 17 > pool) pool = upd1 + c.TN * 17;       // Cholesky panel next to Pxz / K (downdate reads them)
     c.total = o + pool;
     return c;
 }
@@ -422,6 +426,76 @@ __device__ __forceinline__ int cholm_factor(d4 (&acc)[CholM<NT>::NTL], double *L
     return fail;
 }
 
+// ------------------------------------------------------------------ blocked Cholesky on a packed factor in memory
+// Large states (N > 96): the factor does not fit registers or LDS, it lives (packed, lower) in a
+// global workspace that stays in L2 / Infinity Cache.  Left-looking, 16 columns per block step:
+//   1. panel = A[:, J] - L[:, 0:J] L[J, 0:J]^T   one MFMA chain per row tile, fragments read from the
+//      already finished columns in memory, result to an LDS panel ((n - 16J) x 16, ld 17)
+//   2. the 16x16 diagonal tile is factored by wave 0 on the matrix cores (cholm_factor<1>)
+//   3. the rows below are solved against it, one thread per row, and written out.
+template <int NTHREADS, class InitFn>
+__device__ __forceinline__ int chol_blocked_mem(double *Lp, int n, double *panel, double *cb, int *flag,
+                                                int tid, InitFn init)
+{
+    constexpr int NW = NTHREADS / 64;
+    const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int ntc = (n + 15) / 16;
+    double *L11 = cb + 4 * 34;            // packed 16x16 factor of the current diagonal tile
+    int fail = -1;
+    for (int J = 0; J < ntc; ++J) {
+        const int c0 = 16 * J, ncol = (n - c0 < 16) ? (n - c0) : 16;
+        for (int I = J + wave; I < ntc; I += NW) {
+            d4 acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = 16 * I + g + 4 * r, col = c0 + c;
+                double v;
+                if (row < n && col < n) v = (row >= col) ? init(row, col) : init(col, row);
+                else v = (row == col) ? 1.0 : 0.0;
+                acc[r] = v;
+            }
+            const int ra = 16 * I + c, rb = c0 + c;
+            for (int kk = 0; kk < c0; kk += 4) {
+                double af = (ra < n) ? -Lp[pk(n, ra, kk + g)] : 0.0;
+                double bf = (rb < n) ? Lp[pk(n, rb, kk + g)] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) panel[(16 * (I - J) + g + 4 * r) * 17 + c] = acc[r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            d4 a1[1];
+            cholm_load<1>(a1, ncol, lane, [&](int i, int j) { return panel[i * 17 + j]; });
+            int f0 = cholm_factor<1>(a1, L11, ncol, cb, lane);
+            if (lane == 0) *flag = f0;
+        }
+        __syncthreads();
+        if (*flag >= 0) { fail = c0 + *flag; break; }
+        for (int r = tid; r < n - c0; r += NTHREADS) {
+            const int row = c0 + r;
+            if (r < ncol) {
+                for (int b = 0; b <= r; ++b) Lp[pk(n, row, c0 + b)] = L11[pk(ncol, r, b)];
+            } else {
+                double x[16];
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    x[b] = 0.0;
+                    if (b < ncol) {
+                        double sum = panel[r * 17 + b];
+#pragma unroll
+                        for (int q = 0; q < b; ++q) sum -= x[q] * L11[pk(ncol, b, q)];
+                        x[b] = sum / L11[pk(ncol, b, b)];
+                        Lp[pk(n, row, c0 + b)] = x[b];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    return fail;
+}
+
 // ------------------------------------------------------------------ small reductions
 // sum over i in [0, cnt) of term(i), spread over G consecutive lanes (G = 2^k <= 64); every lane of
 // the group gets the total
@@ -660,37 +734,48 @@ template <int NT> struct TileMap {
     __host__ __device__ static constexpr int col(int t) { return t - row(t) * (row(t) + 1) / 2; }
 };
 
+// tiles are dealt round-robin to the waves; with more than TPWMAX tiles per wave the rebuild runs in
+// passes of NW * TPWMAX tiles (large states)
+template <int NT, int NW> struct TilePlan {
+    static constexpr int TPWMAX = 6;
+    static constexpr int TPW_ALL = (TileMap<NT>::NTILES + NW - 1) / NW;
+    static constexpr int TPW = TPW_ALL < TPWMAX ? TPW_ALL : TPWMAX;
+    static constexpr int PER_PASS = NW * TPW;
+    static constexpr int PASSES = (TileMap<NT>::NTILES + PER_PASS - 1) / PER_PASS;
+};
+
 template <int NT, int NW, int T>
 struct MfmaTiles {
-    static constexpr int TPW = (TileMap<NT>::NTILES + NW - 1) / NW;
-    __device__ __forceinline__ static void run(const double (&frag)[NT], d4 (&acc)[TPW], int wave)
+    static constexpr int TPW = TilePlan<NT, NW>::TPW;
+    static constexpr int PER_PASS = TilePlan<NT, NW>::PER_PASS;
+    __device__ __forceinline__ static void run(const double (&frag)[NT], d4 (&acc)[TPW], int wave, int pass)
     {
         if constexpr (T < TileMap<NT>::NTILES) {
-            if ((T % NW) == wave)
-                acc[T / NW] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[TileMap<NT>::row(T)], frag[TileMap<NT>::col(T)],
-                                                                 acc[T / NW], 0, 0, 0);
-            MfmaTiles<NT, NW, T + 1>::run(frag, acc, wave);
+            if ((T % NW) == wave && (T / PER_PASS) == pass)
+                acc[(T % PER_PASS) / NW] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[TileMap<NT>::row(T)], frag[TileMap<NT>::col(T)],
+                                                                              acc[(T % PER_PASS) / NW], 0, 0, 0);
+            MfmaTiles<NT, NW, T + 1>::run(frag, acc, wave, pass);
         }
     }
     // accumulators -> global P (column-major, both triangles).  The tile is written transposed
     // (P is symmetric), so that the 16 lanes of a row group store 128 contiguous bytes.
-    __device__ __forceinline__ static void store(double *gP, int N, const d4 (&acc)[TPW], int wave, int lane)
+    __device__ __forceinline__ static void store(double *gP, int N, const d4 (&acc)[TPW], int wave, int lane, int pass)
     {
         if constexpr (T < TileMap<NT>::NTILES) {
-            if ((T % NW) == wave) {
+            if ((T % NW) == wave && (T / PER_PASS) == pass) {
                 constexpr int I = TileMap<NT>::row(T), J = TileMap<NT>::col(T);
                 int c = 16 * J + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int rr = 16 * I + (lane >> 4) + 4 * r;
                     if (rr < N && c < N) {
-                        double v = 0.5 * acc[T / NW][r];
+                        double v = 0.5 * acc[(T % PER_PASS) / NW][r];
                         gP[c + (size_t)rr * N] = v;
                         if (I != J) gP[rr + (size_t)c * N] = v;
                     }
                 }
             }
-            MfmaTiles<NT, NW, T + 1>::store(gP, N, acc, wave, lane);
+            MfmaTiles<NT, NW, T + 1>::store(gP, N, acc, wave, lane, pass);
         }
     }
 };
@@ -698,8 +783,9 @@ struct MfmaTiles {
 // ------------------------------------------------------------------ the Msckf step kernel
 // predict (optional) + UKF update with applyDelta (optional), one workgroup per filter.
 template <int NT, int NTHREADS>
-__global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_step_kernel(KArgs a)
+__global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) void msckf_step_kernel(KArgs a)
 {
+    constexpr bool BIG = NT > 6;                           // large state: factor + rotation store in the global workspace
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NTHREADS / 64;
     constexpr int GD = Grid<NTHREADS>::GD;
@@ -708,9 +794,10 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
     const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Lay L = a.lay;
     const int N = L.N, Nq = L.Nq, m = a.m, nso3 = L.nso3;
-    const Carve cv = carve_step(L, m, NT);
+    const Carve cv = carve_step(L, m, NT, BIG);
     const int S = cv.S, LDD = cv.LDD;
-    double *Lp = smem + cv.Lp, *mu = smem + cv.mu, *ref = smem + cv.ref, *pn12 = smem + cv.pn12;
+    double *Lp = BIG ? a.wsL + (size_t)bidx * pk_size(N) : smem + cv.Lp;
+    double *mu = smem + cv.mu, *ref = smem + cv.ref, *pn12 = smem + cv.pn12;
     double *delta = smem + cv.delta, *md = smem + cv.md, *colbuf = smem + cv.colbuf, *pool = smem + cv.pool;
     int *ish = reinterpret_cast<int *>(smem + cv.small);      // [0..MAXM) idx, [40] count, [41] outliers, [42] flag, [43] predicted
     int *roff = ish + 48;                                     // nso3 + 1 prefix offsets of the rotation items
@@ -776,6 +863,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
             }
             __syncthreads();
             fail = ish[45];
+        } else if constexpr (BIG) {
+            fail = chol_blocked_mem<NTHREADS>(Lp, N, pool, colbuf, &ish[45], tid, Pin);
         } else {
             fail = chol_packed<NTHREADS, SDN>(Lp, N, colbuf, tid, Pin);
         }
@@ -971,12 +1060,18 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
                         __syncthreads();
                         fail = ish[45];
                     } else {
-                        fail = chol_packed<NTHREADS, SDN>(Lp, N, colbuf, tid, [&](int i, int j) {
+                        auto down = [&](int i, int j) {
                             double p = Pin(i, j);
                             double sum = 0.0;
                             for (int c = 0; c < mmr; ++c) sum += Pxz[i + N * idx[c]] * K[j + N * c];
                             return p - sum;
-                        });
+                        };
+                        if constexpr (BIG) {
+                            double *panel = innov + 2 * round_up(m, 2);      // behind the measurement arrays
+                            fail = chol_blocked_mem<NTHREADS>(Lp, N, panel, colbuf, &ish[45], tid, down);
+                        } else {
+                            fail = chol_packed<NTHREADS, SDN>(Lp, N, colbuf, tid, down);
+                        }
                     }
                     SLK_STAMP(11);
                     if (fail >= 0) {
@@ -984,8 +1079,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
                     } else {
                         // ---- re-drawn sigma points, manifold mean (:664 -> :499-525), covariance (:665)
                         const int W = cv.W;
-                        double *DR = pool;                                // rotation deviations, 3 per stored item
-                        double *Dp = pool + round_up(3 * W, 2);           // [2][KP][LDD] panels
+                        double *DR = BIG ? a.wsDR + (size_t)bidx * 3 * W : pool;   // rotation deviations, 3 per stored item
+                        double *Dp = BIG ? pool : pool + round_up(3 * W, 2);       // [2][KP][LDD] panels
                         // reference = X[0] = mu + delta (:501)
                         for (int t = tid; t < N; t += NTHREADS) {
                             int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
@@ -1030,8 +1125,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
                                 if (sub == 0) md[t] = sum / (double)S;
                             }
                             __syncthreads();
-                            double n2 = 0.0;
-                            for (int t = 0; t < N; ++t) n2 += md[t] * md[t];
+                            double n2 = group_sum<64>(lane, N, [&](int t) { return md[t] * md[t]; });
                             norm = sqrt(n2);
                             for (int t = tid; t < N; t += NTHREADS) {       // reference += mean_delta
                                 int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
@@ -1054,7 +1148,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
                         // panel: vector rows straight from the factor, rotation rows from DR
                         constexpr int TN = 16 * NT;
                         constexpr int RPT = (TN + 63) / 64;                 // rows of D handled per lane
-                        constexpr int TPW = MfmaTiles<NT, NW, 0>::TPW;
+                        constexpr int TPW = TilePlan<NT, NW>::TPW;
                         int rkind[RPT], roffs[RPT], rcnt[RPT];
                         double rm[RPT], rd[RPT], rr[RPT];
 #pragma unroll
@@ -1067,9 +1161,6 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
                                 else { rkind[q] = 2; roffs[q] = 3 * roff[blk] + comp; rcnt[q] = roff[blk + 1] - roff[blk]; }
                             } else if (t >= TN) rkind[q] = 3;
                         }
-                        d4 acc[TPW];
-#pragma unroll
-                        for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
                         auto gen_panel = [&](int p0, double *Dq) __attribute__((always_inline)) {
                             for (int kk = wave; kk < KP; kk += NW) {
                                 int i = p0 + kk;
@@ -1091,23 +1182,28 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 ? 3 : 1)) void msckf_ste
                                 }
                             }
                         };
-                        gen_panel(0, Dp);
-                        __syncthreads();
-                        int pb = 0;
-                        for (int p0 = 0; p0 < S; p0 += KP, pb ^= 1) {
-                            const double *Dc = Dp + pb * KP * LDD;
+                        for (int pass = 0; pass < TilePlan<NT, NW>::PASSES; ++pass) {
+                            d4 acc[TPW];
 #pragma unroll
-                            for (int ks = 0; ks < KP / 4; ++ks) {
-                                double frag[NT];
-#pragma unroll
-                                for (int I = 0; I < NT; ++I) frag[I] = Dc[(4 * ks + (lane >> 4)) * LDD + 16 * I + (lane & 15)];
-                                MfmaTiles<NT, NW, 0>::run(frag, acc, wave);
-                            }
-                            if (p0 + KP < S) gen_panel(p0 + KP, Dp + (pb ^ 1) * KP * LDD);
+                            for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+                            gen_panel(0, Dp);
                             __syncthreads();
+                            int pb = 0;
+                            for (int p0 = 0; p0 < S; p0 += KP, pb ^= 1) {
+                                const double *Dc = Dp + pb * KP * LDD;
+#pragma unroll
+                                for (int ks = 0; ks < KP / 4; ++ks) {
+                                    double frag[NT];
+#pragma unroll
+                                    for (int I = 0; I < NT; ++I) frag[I] = Dc[(4 * ks + (lane >> 4)) * LDD + 16 * I + (lane & 15)];
+                                    MfmaTiles<NT, NW, 0>::run(frag, acc, wave, pass);
+                                }
+                                if (p0 + KP < S) gen_panel(p0 + KP, Dp + (pb ^ 1) * KP * LDD);
+                                __syncthreads();
+                            }
+                            SLK_STAMP(14);
+                            MfmaTiles<NT, NW, 0>::store(gP, N, acc, wave, lane, pass);
                         }
-                        SLK_STAMP(14);
-                        MfmaTiles<NT, NW, 0>::store(gP, N, acc, wave, lane);
                         SLK_STAMP(15);
                     }
                 }

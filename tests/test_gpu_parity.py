@@ -37,7 +37,7 @@ def test_mfma_f64_fragment_layout(slk):
 
 
 # ------------------------------------------------------------------ Msckf
-@pytest.mark.parametrize("k", [0, 1, 4, 8])
+@pytest.mark.parametrize("k", [0, 1, 4, 8, 31])
 def test_msckf_unit_test_scenario_against_golden(slk, k):
     g = np.load(os.path.join(G, "msckf_unit_test.npz"))
     t = sc.msckf_unit_test(k)
@@ -74,7 +74,8 @@ def test_msckf_batch_golden_with_outliers(slk):
         assert mean_err(lay, M[b], g["mean"][b]) <= TOL, b
 
 
-@pytest.mark.parametrize("k,m,B", [(0, 2, 96), (1, 2, 96), (3, 6, 64), (8, 8, 64), (12, 8, 16)])
+@pytest.mark.parametrize("k,m,B", [(0, 2, 96), (1, 2, 96), (3, 6, 64), (8, 8, 64), (12, 8, 16), (14, 8, 6), (15, 8, 6),
+                                   (31, 8, 5)])
 def test_msckf_step_against_oracle(slk, k, m, B):
     s = sc.synthetic_msckf(B, k, m=m, seed=100 + k)
     lay = o.layout(o.MULTI, k)
@@ -193,9 +194,9 @@ def test_api_misuse_is_rejected(slk):
     assert lib.slk_update(f._h, slk.MM_FEATURE_PROJ, None, 0, z.ctypes.data, 3, R.ctypes.data, 0, 1, slk.HOST) == slk.E_INVALID
     assert lib.slk_update(f._h, 77, None, 0, z.ctypes.data, 2, R.ctypes.data, 0, 1, slk.HOST) == slk.E_INVALID
     assert lib.slk_predict(f._h, slk.PM_DELTA_POSE, None, 0, None, 0, slk.HOST) == slk.E_INVALID
-    big = slk.Msckf(np.tile(o.identity_state(o.layout(o.MULTI, 20)), (1, 1)), np.eye(132))
+    big = slk.Msckf(np.tile(o.identity_state(o.layout(o.MULTI, 40)), (1, 1)), np.eye(252))
     with pytest.raises(slk.SlkError):
-        big.predict(slk.PM_DELTA_POSE, s["u"][0], s["Q"])      # N = 132 exceeds the LDS-resident kernels
+        big.predict(slk.PM_DELTA_POSE, s["u"][0], s["Q"])      # N = 252 exceeds what the kernels are built for (208)
 
 
 # ------------------------------------------------------------------ full-size properties (BASELINE cfg3)
