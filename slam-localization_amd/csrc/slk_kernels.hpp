@@ -400,11 +400,12 @@ struct CholMCols {
                         nfrag[I] = -f;
                         if (rho >= kap && rho < n && kap < n) Lp[pk(n, rho, kap)] = f;
                     }
-                    // 4. rank-4 update of the trailing tiles
+                    // 4. rank-4 update of the trailing tiles, tile column by tile column: the tiles the NEXT
+                    // step publishes (column JK, then JK+1) retire first, the rest drains under its prologue
 #pragma unroll
-                    for (int I = JK; I < NT; ++I)
+                    for (int J = JK; J < NT; ++J)
 #pragma unroll
-                        for (int J = JK; J <= I; ++J)
+                        for (int I = J; I < NT; ++I)
                             acc[tile_idx(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(nfrag[I], frag[J], acc[tile_idx(I, J)], 0, 0, 0);
                 }
             }
@@ -604,21 +605,43 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
     SLK_STAMP(5);
     // S = cov(Z) + R (:238), covXZ (:239 -> :635-657).  X_i [-] mu = +-L.col(j) (and 0 for X_0):
     // covXZ = 1/2 L * (Z_{2j+1} - Z_{2j+2})_j ; exact while every rotation column is shorter than pi.
+    // Both are small GEMMs and run on the matrix cores: covXZ row tile I = L[16I.., :] * DZ (only the
+    // k-steps up to the diagonal, L is lower triangular), S = dZ^T dZ with K = 2N+1.
     const double *R = a.R + (size_t)bidx * a.r_stride;
-    for (int e = tid / 4; e < m * m; e += NTHREADS / 4) {
-        int r = e % m, c = e / m;
-        double zr = zbar[r], zc = zbar[c];
-        double sum = group_sum<4>(tid & 3, S, [&](int i) { return (Z[i * m + r] - zr) * (Z[i * m + c] - zc); });
-        if ((tid & 3) == 0) Sm[e] = 0.5 * sum + R[e];
-    }
     const bool wrap = *flag != 0;
-    for (int e = tid; e < N * m; e += NTHREADS) {
-        int t = e % N, r = e / N;
-        double sum = 0.0;
-        if (!wrap) {
-#pragma unroll 4
-            for (int j = 0; j <= t; ++j) sum += Lp[pk(N, t, j)] * DZ[j * m + r];
-        } else {
+    constexpr int NW = NTHREADS / 64;
+    const int lane = tid & 63, wave = tid >> 6, fc = lane & 15, fg = lane >> 4;
+    const int ntr = (N + 15) / 16, ntm = (m + 15) / 16;
+    if (!wrap) {
+        for (int e = wave; e < ntr * ntm; e += NW) {
+            const int I = e % ntr, jt = e / ntr, row = 16 * I + fc, cz = 16 * jt + fc;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            const int kend = (16 * I + 16 < N) ? (16 * I + 16) : N;
+            for (int k0 = 0; k0 < kend; k0 += 16) {
+                // four k-steps per trip: all eight operand loads are issued (branch-free: clamped
+                // address, then select) before the first MFMA, so LDS latency is paid once per trip
+                double af[4], bf[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int col = k0 + 4 * u + fg;
+                    const bool oka = row < N && col <= row && col < kend, okb = col < kend && cz < m;
+                    const double av = Lp[oka ? pk(N, row, col) : 0], bv = DZ[okb ? col * m + cz : 0];
+                    af[u] = oka ? av : 0.0;
+                    bf[u] = okb ? bv : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], bf[u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int orow = 16 * I + fg + 4 * r;
+                if (orow < N && cz < m) Pxz[orow + N * cz] = 0.5 * acc[r];
+            }
+        }
+    } else {
+        for (int e = tid; e < N * m; e += NTHREADS) {
+            int t = e % N, r = e / N;
+            double sum = 0.0;
             int blk = -1, comp = 0, s = t2s(L, t, blk, comp), t0 = t - comp;
             for (int j = 0; j <= t; ++j) {
                 double w = 1.0;
@@ -629,10 +652,45 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
                 }
                 sum += w * Lp[pk(N, t, j)] * DZ[j * m + r];
             }
+            Pxz[e] = 0.5 * sum;
         }
-        Pxz[e] = 0.5 * sum;
     }
+    SLK_STAMP(16);
+    // S: lower tiles (a >= b) of the m x m matrix
+    for (int e = wave; e < ntm * (ntm + 1) / 2; e += NW) {      // wave 0 has the shortest covXZ tile
+        int ta = 0;
+        while ((ta + 1) * (ta + 2) / 2 <= e) ++ta;
+        const int tb = e - ta * (ta + 1) / 2;
+        const int ra = 16 * ta + fc, rb = 16 * tb + fc;
+        const double za = (ra < m) ? zbar[ra] : 0.0, zb = (rb < m) ? zbar[rb] : 0.0;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        d4 accp[4] = {acc, acc, acc, acc};      // four independent accumulation chains
+        for (int k0 = 0; k0 < S; k0 += 32) {
+            double af[8], bf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = k0 + 4 * u + fg;
+                const bool oka = i < S && ra < m, okb = i < S && rb < m;
+                const double av = Z[oka ? i * m + ra : 0], bv = Z[okb ? i * m + rb : 0];
+                af[u] = oka ? av - za : 0.0;
+                bf[u] = okb ? bv - zb : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) accp[u & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], bf[u], accp[u & 3], 0, 0, 0);
+        }
+        acc = (accp[0] + accp[1]) + (accp[2] + accp[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int orow = 16 * ta + fg + 4 * r, ocol = 16 * tb + fc;
+            if (orow < m && ocol < m) {
+                Sm[orow + m * ocol] = 0.5 * acc[r] + R[orow + m * ocol];
+                if (ta != tb) Sm[ocol + m * orow] = 0.5 * acc[r] + R[ocol + m * orow];
+            }
+        }
+    }
+    SLK_STAMP(17);
     __syncthreads();
+    SLK_STAMP(18);
 }
 
 // ------------------------------------------------------------------ 12-DOF predict phase

@@ -35,12 +35,16 @@ void run(int blocks, int threads, int iters)
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long c; hipMemcpy(&c, cyc, sizeof(c), hipMemcpyDeviceToHost);
     double nm = (double)blocks * (threads / 64) * iters * NACC;
-    printf("NACC=%d blocks=%d threads=%d: %.3f ms, %.2f TFLOP/s fp64, %.1f cycles per MFMA per wave (block 0)\n",
-           NACC, blocks, threads, ms, nm * 2048 / (ms * 1e-3) / 1e12, (double)c / (iters * NACC));
+    double waves_per_simd = (double)blocks * (threads / 64) / 1024.0;
+    printf("NACC=%d blocks=%d threads=%d (%.0f waves/SIMD): %.3f ms, %.2f TFLOP/s fp64, %.1f ns per MFMA per wave, s_memtime %.1f ticks per MFMA (block 0)\n",
+           NACC, blocks, threads, waves_per_simd, ms, nm * 2048 / (ms * 1e-3) / 1e12, ms * 1e6 / ((double)iters * NACC), (double)c / (iters * NACC));
     hipFree(out); hipFree(cyc);
 }
 int main()
 {
+    run<1>(256, 256, 20000);       // one dependent chain per wave, ONE wave per SIMD: exposes the dependent-issue latency
+    run<2>(256, 256, 20000);
+    run<3>(256, 256, 20000);
     run<1>(256 * 4, 256, 20000);   // one dependent chain per wave, 4 waves per SIMD
     run<4>(256, 256, 20000);       // 4 independent accumulators, one wave per SIMD
     run<4>(256 * 2, 256, 20000);   // two waves per SIMD

@@ -59,6 +59,10 @@ def main():
              "chol2", "mean loop", "final Drot", "MFMA rebuild", "acc->LDS+store"]
     for i, name in enumerate(names):
         print(f"  {name:16s} {np.median(d[:, i]):10.0f}  {100 * np.median(d[:, i]) / np.median(tot):5.1f} %")
+    if (t[ok][:, 16] > 0).all():      # sub-stamps of the moments phase (thread 0 = wave 0)
+        x = t[ok].astype(np.float64)
+        print(f"  moments detail (wave 0): stamp5->Pxz done {np.median(x[:, 16] - x[:, 5]):.0f}, "
+              f"S tiles {np.median(x[:, 17] - x[:, 16]):.0f}, barrier wait {np.median(x[:, 18] - x[:, 17]):.0f}")
 
 
 if __name__ == "__main__":

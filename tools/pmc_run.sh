@@ -30,3 +30,6 @@ run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_A
 run sq2 SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM 2>&1 | tee gpurun_out/pmc_${TAG}_sq2.txt
 run tcc1 FETCH_SIZE 2>&1 | tee gpurun_out/pmc_${TAG}_fetch.txt
 run tcc2 WRITE_SIZE 2>&1 | tee gpurun_out/pmc_${TAG}_write.txt
+if [ "${2:-}" = "icache" ]; then
+run ic SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES 2>&1 | tee gpurun_out/pmc_${TAG}_icache.txt
+fi
