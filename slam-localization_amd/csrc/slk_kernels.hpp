@@ -101,7 +101,11 @@ __host__ __device__ __forceinline__ int pk(int n, int i, int j) { return ((j * (
 __host__ __device__ __forceinline__ int pk_size(int n) { return n * (n + 1) / 2; }
 __device__ __forceinline__ double Lz(const double *Lp, int n, int t, int j)
 {
-    return (j <= t) ? Lp[pk(n, t, j)] : 0.0;
+    // branch-free: always load (index clamped into the array), then select -- lets the loads of one
+    // sigma point issue back to back instead of one exec-masked block each
+    const bool in = j <= t;
+    const double v = Lp[in ? pk(n, t, j) : 0];
+    return in ? v : 0.0;
 }
 
 // ------------------------------------------------------------------ LDS carve (in doubles)
@@ -157,7 +161,7 @@ __device__ __forceinline__ Sig sig_of(int i)
 }
 __device__ __forceinline__ double pert(const double *Lp, int n, const double *delta, int t, const Sig &s)
 {
-    double l = (s.sgn != 0.0) ? s.sgn * Lz(Lp, n, t, s.j) : 0.0;
+    double l = s.sgn * Lz(Lp, n, t, s.j);       // sgn = 0 for X_0
     return delta ? (delta[t] + l) : l;
 }
 __device__ __forceinline__ Quat sigma_quat(const Lay &L, const double *mu, const double *Lp,
@@ -456,10 +460,18 @@ __device__ __forceinline__ int chol_blocked_mem(double *Lp, int n, double *panel
                 acc[r] = v;
             }
             const int ra = 16 * I + c, rb = c0 + c;
-            for (int kk = 0; kk < c0; kk += 4) {
-                double af = (ra < n) ? -Lp[pk(n, ra, kk + g)] : 0.0;
-                double bf = (rb < n) ? Lp[pk(n, rb, kk + g)] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf, acc, 0, 0, 0);
+            const bool oka = ra < n, okb = rb < n;
+            for (int kk = 0; kk < c0; kk += 16) {          // c0 is a multiple of 16: four k-steps per trip, loads first
+                double af[4], bf[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int col = kk + 4 * u + g;
+                    const double av = Lp[oka ? pk(n, ra, col) : 0], bv = Lp[okb ? pk(n, rb, col) : 0];
+                    af[u] = oka ? -av : 0.0;
+                    bf[u] = okb ? bv : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], bf[u], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) panel[(16 * (I - J) + g + 4 * r) * 17 + c] = acc[r];
@@ -795,7 +807,7 @@ template <int NT> struct TileMap {
 // tiles are dealt round-robin to the waves; with more than TPWMAX tiles per wave the rebuild runs in
 // passes of NW * TPWMAX tiles (large states)
 template <int NT, int NW> struct TilePlan {
-    static constexpr int TPWMAX = 6;
+    static constexpr int TPWMAX = (NT > 6) ? 12 : 6;      // the large-state kernel runs one workgroup per CU: registers to spare
     static constexpr int TPW_ALL = (TileMap<NT>::NTILES + NW - 1) / NW;
     static constexpr int TPW = TPW_ALL < TPWMAX ? TPW_ALL : TPWMAX;
     static constexpr int PER_PASS = NW * TPW;
@@ -1221,19 +1233,30 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
                         }
                         auto gen_panel = [&](int p0, double *Dq) __attribute__((always_inline)) {
                             for (int kk = wave; kk < KP; kk += NW) {
-                                int i = p0 + kk;
-                                int j = (i - 1) >> 1;
-                                double sgn = (i & 1) ? 1.0 : -1.0;
+                                const int i = p0 + kk;
+                                const int j = (i - 1) >> 1;
+                                const double sgn = (i & 1) ? 1.0 : -1.0;
+                                const int jb = ((j * (2 * N - j + 1)) >> 1) - j;          // pk(N, t, j) = jb + t
+                                // all loads of this column first (branch-free: clamped address, select later)
+                                double lv[RPT];
 #pragma unroll
                                 for (int q = 0; q < RPT; ++q) {
-                                    int t = lane + 64 * q;
+                                    const int t = lane + 64 * q;
+                                    const bool vec = rkind[q] == 1 && i > 0 && i < S && j <= t;
+                                    const bool rot = rkind[q] == 2 && i < S;
+                                    const double *src = rot ? DR + (roffs[q] + 3 * (i < rcnt[q] ? i : 0)) : Lp + (vec ? jb + t : 0);
+                                    lv[q] = *src;
+                                }
+#pragma unroll
+                                for (int q = 0; q < RPT; ++q) {
+                                    const int t = lane + 64 * q;
                                     double v = 0.0;
                                     if (i < S) {
                                         if (rkind[q] == 1) {
-                                            double l = (i > 0 && j <= t) ? sgn * Lp[pk(N, t, j)] : 0.0;
+                                            const double l = (i > 0 && j <= t) ? sgn * lv[q] : 0.0;
                                             v = (rm[q] + (rd[q] + l)) - rr[q];
                                         } else if (rkind[q] == 2) {
-                                            v = DR[roffs[q] + 3 * (i < rcnt[q] ? i : 0)];
+                                            v = lv[q];
                                         }
                                     }
                                     if (rkind[q] != 3) Dq[kk * LDD + t] = v;
