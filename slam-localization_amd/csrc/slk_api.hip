@@ -213,11 +213,7 @@ static int launch_msckf(slk_filter *f, const KArgs &a)
     case 1: return launch_msckf_inst<1, 64>(f, a);
     case 2: return launch_msckf_inst<2, 64>(f, a);
     case 3: return launch_msckf_inst<3, 256>(f, a);
-    case 4: {
-        static const int force64 = getenv("SLK_EXPERIMENT_WAVE_PER_FILTER") ? 1 : 0;   // experiment switch, not a product knob
-        if (force64) return launch_msckf_inst<4, 64>(f, a);
-        return launch_msckf_inst<4, 256>(f, a);
-    }
+    case 4: return launch_msckf_inst<4, 256>(f, a);
     case 5: return launch_msckf_inst<5, 256>(f, a);
     case 6: return launch_msckf_inst<6, 256>(f, a);
     case 7: case 8: return launch_msckf_inst<8, 256>(f, a);

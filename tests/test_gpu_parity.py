@@ -278,3 +278,77 @@ def test_usckf_spd_predict_update_against_golden_and_oracle(slk):
         assert mean_err(lay, M[b], g["mean"][b]) <= TOL
     np.testing.assert_array_equal(h.PkAugmentedState(), P)
     np.testing.assert_array_equal(h.muState(), M)
+
+
+def test_usckf_whole_vector_gate_and_other_models(slk):
+    # Usckf.hpp:262-302 with a chi-square gate (mt) instead of accept_any: accepted and rejected filters
+    s = sc.synthetic_usckf(4, seed=77)
+    z = s["z"].copy()
+    z[1] += 5.0                                     # filter 1: gross innovation -> rejected by chi2(3)
+    f = slk.Usckf(mean=s["mean"], P=s["P"], nfk=3, nfkl=9)
+    f.update(z, slk.MM_VO_RELATIVE, None, s["R"], gate=3)
+    st, out = f.status(), f.outliers()
+    assert out[1] == 1 and st[1] == slk.ST_ALL_REJECTED and (np.delete(out, 1) == 0).all()
+    lay = o.layout(o.AUGMENTED, 0, 3, 9)
+    P, M = f.PkAugmentedState(), f.muState()
+    for b in range(4):
+        g = o.Usckf(nfk=3, nfkl=9, mean=s["mean"][b], P=s["P"][b])
+        stc, acc = g.update(z[b], o.mm_vo_relative(), s["R"], gate_dof=3)
+        assert stc == 0 and acc == (0 if b == 1 else 1)
+        assert rel(P[b], g.P) <= TOL and mean_err(lay, M[b], g.mean) <= TOL
+    # feature-projection model on the Usckf layout (pose index = statek / statek_l / statek_i)
+    feat = np.zeros((4, 2, 4))
+    for b in range(4):
+        for j, c in enumerate((0, 2)):
+            p = s["mean"][b, 13 * c:13 * c + 3]
+            q = s["mean"][b, 13 * c + 3:13 * c + 7]
+            feat[b, j, 0:3] = p + sc.quat_rotate(q, np.array([0.3 * (j + 1), -0.2, 5.0 + j]))
+            feat[b, j, 3] = c
+    zz = np.tile(np.array([0.06, -0.04, 0.1, -0.03]), (4, 1))
+    f2 = slk.Usckf(mean=s["mean"], P=s["P"], nfk=3, nfkl=9)
+    f2.update(zz, slk.MM_FEATURE_PROJ, feat, 0.01 * np.eye(4))
+    assert (f2.status() == 0).all()
+    P2, M2 = f2.PkAugmentedState(), f2.muState()
+    for b in range(4):
+        g = o.Usckf(nfk=3, nfkl=9, mean=s["mean"][b], P=s["P"][b])
+        stc, acc = g.update(zz[b], o.mm_feature_proj(feat[b]), 0.01 * np.eye(4))
+        assert stc == 0 and acc == 1
+        assert rel(P2[b], g.P) <= TOL and mean_err(lay, M2[b], g.mean) <= TOL
+
+
+def test_usckf_functor_path_equals_registered_model(slk):
+    from oracle import np_check as npc
+    s = sc.synthetic_usckf(2, seed=78)
+    lay = o.layout(o.AUGMENTED, 0, 3, 9)
+    a = slk.Usckf(mean=s["mean"], P=s["P"], nfk=3, nfkl=9)
+    b = slk.Usckf(mean=s["mean"], P=s["P"], nfk=3, nfkl=9)
+    a.predict(slk.PM_CONST_VELOCITY, s["u"], s["Q"])
+    a.update(s["z"], slk.MM_VO_RELATIVE, None, s["R"])
+    lib = slk.load_library()
+    X = b.predict_sigma_points()
+    Y = np.ascontiguousarray([[npc.pm_const_velocity(x, s["u"][i, 0:3], s["u"][i, 3:6], s["u"][i, 6]) for x in X[i]]
+                              for i in range(2)])
+    Qc = np.ascontiguousarray(s["Q"].T)
+    assert lib.slk_predict_from_sigma(b._h, Y.ctypes.data, Qc.ctypes.data, 0, slk.HOST) == 0
+    b.update_functor(s["z"], lambda x: npc.mm_vo_relative(x, 3), s["R"])
+    for i in range(2):
+        assert rel(b.PkAugmentedState()[i], a.PkAugmentedState()[i]) <= TOL
+        assert mean_err(lay, b.muState()[i], a.muState()[i]) <= TOL
+
+
+def test_msckf_window_resize_keeps_working(slk):
+    # sliding window: the caller changes the clone set (Msckf.hpp:381-395): resize, upload, step
+    s4 = sc.synthetic_msckf(3, 4, m=4, seed=79)
+    s6 = sc.synthetic_msckf(3, 6, m=4, seed=80)
+    f = slk.Msckf(s4["mean"], s4["P"])
+    f.step(slk.PM_DELTA_POSE, s4["u"], s4["Q"], s4["z"], slk.MM_FEATURE_PROJ, s4["feat"], s4["R"])
+    assert slk.load_library().slk_msckf_resize(f._h, 6) == 0 and f.N == 48
+    f.set_state(s6["mean"], s6["P"])
+    f.clear_status()
+    f.step(slk.PM_DELTA_POSE, s6["u"], s6["Q"], s6["z"], slk.MM_FEATURE_PROJ, s6["feat"], s6["R"])
+    mean, P = s6["mean"].copy(), s6["P"].copy()
+    st, out = o.msckf_step_batch(6, 4, 1, mean, P, s6["u"], s6["feat"], s6["z"], s6["Q"], s6["R"])
+    lay = o.layout(o.MULTI, 6)
+    for b in range(3):
+        assert rel(f.getPk()[b], P[b].reshape(48, 48).T) <= TOL
+        assert mean_err(lay, f.muState()[b], mean[b]) <= TOL
