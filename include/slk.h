@@ -147,6 +147,13 @@ int slk_usckf_set_measurement(slk_filter *f, int mode, const double *z, int n, c
 /* Msckf sliding window: caller-side push/pop on muState().sensorsk + setPk (Msckf.hpp:381-395) */
 int slk_msckf_resize(slk_filter *f, int n_clones);
 
+/* ---- arithmetic of the covariance rebuild (Msckf.hpp:665 -> :574-589): SLK_PREC_F64 (default, the
+ *      parity path), SLK_PREC_F32 (fp32 MFMA) or SLK_PREC_BF16 (bf16 operands, fp32 accumulation).
+ *      The reduced modes exist for the tolerance sweep of BASELINE.json config 5; the reference is
+ *      double throughout (State.hpp:37-38). ---- */
+enum { SLK_PREC_F64 = 0, SLK_PREC_F32 = 1, SLK_PREC_BF16 = 2 };
+int slk_set_rebuild_precision(slk_filter *f, int mode);
+
 /* ---- results of the last update / accumulated status ---- */
 int slk_get_outliers(slk_filter *f, unsigned *outliers /* [B], return value of Msckf::update :276 */, int where);
 int slk_get_status(slk_filter *f, int *status /* [B] */, int where);

@@ -45,6 +45,7 @@ struct slk_filter {
     Stage st_u, st_Q, st_mp, st_z, st_R, st_X, st_Z, st_tmpP, st_tmpM;
     Stage ws_L, ws_DR;            // large-state workspaces (N > 96), allocated on first use
     hipEvent_t ev0, ev1;
+    int rebuild_prec = 0;
 };
 
 static Lay make_lay(int kind, int k, int nfk, int nfkl)
@@ -266,6 +267,7 @@ static void base_args(slk_filter *f, KArgs &a)
     a.B = f->B;
     a.lay = f->lay;
     a.mean = f->d_mean; a.P = f->d_P; a.status = f->d_status; a.outliers = f->d_outliers;
+    a.rebuild_prec = f->rebuild_prec;
 }
 
 static int pm_inputs(int model) { return model == SLK_PM_CONST_VELOCITY ? 7 : (model == SLK_PM_DELTA_POSE ? 13 : 0); }
@@ -451,6 +453,13 @@ int slk_clear_status(slk_filter *f)
     if (!f) return SLK_E_INVALID;
     HIPCHECK(hipSetDevice(f->cfg.device));
     HIPCHECK(hipMemsetAsync(f->d_status, 0, (size_t)f->B * sizeof(int), f->stream));
+    return SLK_OK;
+}
+
+int slk_set_rebuild_precision(slk_filter *f, int mode)
+{
+    if (!f || mode < SLK_PREC_F64 || mode > SLK_PREC_BF16) return SLK_E_INVALID;
+    f->rebuild_prec = mode;
     return SLK_OK;
 }
 

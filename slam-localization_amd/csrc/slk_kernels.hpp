@@ -14,6 +14,8 @@
 namespace slk {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 
 constexpr int KP = 8;        // sigma points per rebuild panel (2 MFMA k-steps), double-buffered
 constexpr int MAXM = 32;     // max measurement rows handled on chip
@@ -32,6 +34,7 @@ struct KArgs {
     const double *R; int r_stride; int gate; const double *Zext;
     // tier B sigma-point emission: 1 = predict sigma points, 2 = update sigma points
     int emit; double *Xout;
+    int rebuild_prec;     // covariance rebuild arithmetic: 0 = fp64 (parity path), 1 = fp32 MFMA, 2 = bf16 inputs / fp32 accumulate
     double *wsL, *wsDR;   // global workspaces of the large-state path (N > 96): packed factor, rotation deviations
     long long *dbg;   // phase stamps, diagnostic builds (-DSLK_STAMPS) only; always null in the product
 };
@@ -850,6 +853,52 @@ struct MfmaTiles {
     }
 };
 
+// Reduced-precision variants of the rebuild for the precision sweep of BASELINE config 5 (never the
+// parity path): fp32 operands on v_mfma_f32_16x16x4_f32, or bf16 operands / fp32 accumulation on
+// v_mfma_f32_16x16x32_bf16.  fp32 result layout: lane l, register r -> row 4*(l>>4) + r, col l&15.
+template <int NT, int NW, int T>
+struct MfmaTiles32 {
+    static constexpr int TPW = TilePlan<NT, NW>::TPW;
+    static constexpr int PER_PASS = TilePlan<NT, NW>::PER_PASS;
+    __device__ __forceinline__ static void run(const float (&frag)[NT], f4 (&acc)[TPW], int wave, int pass)
+    {
+        if constexpr (T < TileMap<NT>::NTILES) {
+            if ((T % NW) == wave && (T / PER_PASS) == pass)
+                acc[(T % PER_PASS) / NW] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[TileMap<NT>::row(T)], frag[TileMap<NT>::col(T)],
+                                                                             acc[(T % PER_PASS) / NW], 0, 0, 0);
+            MfmaTiles32<NT, NW, T + 1>::run(frag, acc, wave, pass);
+        }
+    }
+    __device__ __forceinline__ static void run_bf16(const b8 (&frag)[NT], f4 (&acc)[TPW], int wave, int pass)
+    {
+        if constexpr (T < TileMap<NT>::NTILES) {
+            if ((T % NW) == wave && (T / PER_PASS) == pass)
+                acc[(T % PER_PASS) / NW] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag[TileMap<NT>::row(T)], frag[TileMap<NT>::col(T)],
+                                                                               acc[(T % PER_PASS) / NW], 0, 0, 0);
+            MfmaTiles32<NT, NW, T + 1>::run_bf16(frag, acc, wave, pass);
+        }
+    }
+    __device__ __forceinline__ static void store(double *gP, int N, const f4 (&acc)[TPW], int wave, int lane, int pass)
+    {
+        if constexpr (T < TileMap<NT>::NTILES) {
+            if ((T % NW) == wave && (T / PER_PASS) == pass) {
+                constexpr int I = TileMap<NT>::row(T), J = TileMap<NT>::col(T);
+                int c = 16 * J + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int rr = 16 * I + 4 * (lane >> 4) + r;
+                    if (rr < N && c < N) {
+                        double v = 0.5 * (double)acc[(T % PER_PASS) / NW][r];
+                        gP[c + (size_t)rr * N] = v;
+                        if (I != J) gP[rr + (size_t)c * N] = v;
+                    }
+                }
+            }
+            MfmaTiles32<NT, NW, T + 1>::store(gP, N, acc, wave, lane, pass);
+        }
+    }
+};
+
 // ------------------------------------------------------------------ the Msckf step kernel
 // predict (optional) + UKF update with applyDelta (optional), one workgroup per filter.
 template <int NT, int NTHREADS>
@@ -1263,6 +1312,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
                                 }
                             }
                         };
+                        if (a.rebuild_prec == 0) {
                         for (int pass = 0; pass < TilePlan<NT, NW>::PASSES; ++pass) {
                             d4 acc[TPW];
 #pragma unroll
@@ -1284,6 +1334,69 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
                             }
                             SLK_STAMP(14);
                             MfmaTiles<NT, NW, 0>::store(gP, N, acc, wave, lane, pass);
+                        }
+                        } else if (a.rebuild_prec == 1) {
+                            // ---- precision sweep: fp32 operands and accumulation
+                            for (int pass = 0; pass < TilePlan<NT, NW>::PASSES; ++pass) {
+                                f4 acc[TPW];
+#pragma unroll
+                                for (int q = 0; q < TPW; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
+                                gen_panel(0, Dp);
+                                __syncthreads();
+                                int pb = 0;
+                                for (int p0 = 0; p0 < S; p0 += KP, pb ^= 1) {
+                                    const double *Dc = Dp + pb * KP * LDD;
+#pragma unroll
+                                    for (int ks = 0; ks < KP / 4; ++ks) {
+                                        float frag[NT];
+#pragma unroll
+                                        for (int I = 0; I < NT; ++I)
+                                            frag[I] = (float)Dc[(4 * ks + (lane >> 4)) * LDD + 16 * I + (lane & 15)];
+                                        MfmaTiles32<NT, NW, 0>::run(frag, acc, wave, pass);
+                                    }
+                                    if (p0 + KP < S) gen_panel(p0 + KP, Dp + (pb ^ 1) * KP * LDD);
+                                    __syncthreads();
+                                }
+                                MfmaTiles32<NT, NW, 0>::store(gP, N, acc, wave, lane, pass);
+                            }
+                        } else {
+                            // ---- precision sweep: bf16 operands, fp32 accumulation, 32 sigma points per MFMA.
+                            // Panel = bf16 [16*NT rows][32 sigma points] (64-byte rows), single-buffered.
+                            __bf16 *Db = reinterpret_cast<__bf16 *>(Dp);
+                            for (int pass = 0; pass < TilePlan<NT, NW>::PASSES; ++pass) {
+                                f4 acc[TPW];
+#pragma unroll
+                                for (int q = 0; q < TPW; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
+                                for (int p0 = 0; p0 < S; p0 += 32) {
+                                    for (int kk = wave; kk < 32; kk += NW) {
+                                        const int i = p0 + kk;
+                                        const int j = (i - 1) >> 1;
+                                        const double sgn = (i & 1) ? 1.0 : -1.0;
+#pragma unroll
+                                        for (int q = 0; q < RPT; ++q) {
+                                            const int t = lane + 64 * q;
+                                            double v = 0.0;
+                                            if (i < S) {
+                                                if (rkind[q] == 1) {
+                                                    double l = (i > 0 && j <= t) ? sgn * Lp[pk(N, t, j)] : 0.0;
+                                                    v = (rm[q] + (rd[q] + l)) - rr[q];
+                                                } else if (rkind[q] == 2) {
+                                                    v = DR[roffs[q] + 3 * (i < rcnt[q] ? i : 0)];
+                                                }
+                                            }
+                                            if (rkind[q] != 3) Db[t * 32 + kk] = (__bf16)(float)v;
+                                        }
+                                    }
+                                    __syncthreads();
+                                    b8 frag[NT];
+#pragma unroll
+                                    for (int I = 0; I < NT; ++I)
+                                        frag[I] = *reinterpret_cast<const b8 *>(Db + (16 * I + (lane & 15)) * 32 + 8 * (lane >> 4));
+                                    MfmaTiles32<NT, NW, 0>::run_bf16(frag, acc, wave, pass);
+                                    __syncthreads();
+                                }
+                                MfmaTiles32<NT, NW, 0>::store(gP, N, acc, wave, lane, pass);
+                            }
                         }
                         SLK_STAMP(15);
                     }

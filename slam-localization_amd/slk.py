@@ -30,7 +30,7 @@ EXPORTS = [
     "slk_step", "slk_predict_sigma_points", "slk_predict_from_sigma", "slk_update_sigma_points",
     "slk_update_from_sigma", "slk_usckf_cloning", "slk_usckf_set_measurement", "slk_msckf_resize",
     "slk_get_outliers", "slk_get_status", "slk_clear_status", "slk_sync", "slk_timer_start", "slk_timer_stop",
-    "slk_selftest_mfma",
+    "slk_selftest_mfma", "slk_set_rebuild_precision",
 ]
 
 
@@ -82,6 +82,7 @@ def load_library(path=None):
     lib.slk_get_status.argtypes = [vp, vp, ip]
     lib.slk_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.slk_selftest_mfma.argtypes = [ip]
+    lib.slk_set_rebuild_precision.argtypes = [vp, ip]
     if path is None:
         _lib = lib
     return lib
@@ -227,6 +228,10 @@ class _FilterBatch:
         o = np.zeros(self.B, dtype=np.uint32)
         _check(self._lib.slk_get_outliers(self._h, o.ctypes.data, HOST), "slk_get_outliers")
         return o
+
+    def set_rebuild_precision(self, mode):
+        """0 = fp64 (parity path), 1 = fp32 MFMA, 2 = bf16 operands / fp32 accumulation (precision sweep only)."""
+        _check(self._lib.slk_set_rebuild_precision(self._h, int(mode)), "slk_set_rebuild_precision")
 
     def sync(self):
         _check(self._lib.slk_sync(self._h), "slk_sync")
