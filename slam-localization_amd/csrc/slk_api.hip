@@ -255,7 +255,9 @@ static int launch_usckf(slk_filter *f, const KArgs &a)
 
 #ifdef SLK_STAMPS
 static long long *g_dbg = nullptr;
+static int g_stop = 0;
 extern "C" void slk_debug_set_stamps(long long *device_buffer) { g_dbg = device_buffer; }   // [B][32], diagnostic build only
+extern "C" void slk_debug_set_stop(int stamp) { g_stop = stamp; }                          // 0 = run to the end
 #endif
 
 static void base_args(slk_filter *f, KArgs &a)
@@ -263,6 +265,7 @@ static void base_args(slk_filter *f, KArgs &a)
     memset(&a, 0, sizeof(a));
 #ifdef SLK_STAMPS
     a.dbg = g_dbg;
+    a.stop = g_stop;
 #endif
     a.B = f->B;
     a.lay = f->lay;

@@ -37,13 +37,16 @@ struct KArgs {
     int rebuild_prec;     // covariance rebuild arithmetic: 0 = fp64 (parity path), 1 = fp32 MFMA, 2 = bf16 inputs / fp32 accumulate
     double *wsL, *wsDR;   // global workspaces of the large-state path (N > 96): packed factor, rotation deviations
     long long *dbg;   // phase stamps, diagnostic builds (-DSLK_STAMPS) only; always null in the product
+    int stop;         // diagnostic builds: leave the kernel after this stamp (per-phase instruction counts)
 };
 
 #ifdef SLK_STAMPS
-#define SLK_STAMP(i) do { if (tid == 0 && a.dbg) a.dbg[(size_t)bidx * 32 + (i)] = clock64(); } while (0)
+#define SLK_STAMP(i) do { if (tid == 0 && a.dbg) a.dbg[(size_t)bidx * 32 + (i)] = clock64(); if (a.stop > 0 && a.stop == (i)) return; } while (0)
+#define SLK_STAMP_NR(i) do { if (tid == 0 && a.dbg) a.dbg[(size_t)bidx * 32 + (i)] = clock64(); } while (0)
 #define SLK_NOTE(i, v) do { if (tid == 0 && a.dbg) a.dbg[(size_t)bidx * 32 + (i)] = (long long)(v); } while (0)
 #else
 #define SLK_STAMP(i) do { } while (0)
+#define SLK_STAMP_NR(i) do { } while (0)
 #define SLK_NOTE(i, v) do { } while (0)
 #endif
 
@@ -173,6 +176,42 @@ __device__ __forceinline__ Quat sigma_quat(const Lay &L, const double *mu, const
     int to = so3_toff(L, b);
     return qmul(ldq(mu + so3_soff(L, b)),
                 so3_exp(pert(Lp, L.N, delta, to, s), pert(Lp, L.N, delta, to + 1, s), pert(Lp, L.N, delta, to + 2, s)));
+}
+
+// ------------------------------------------------------------------ Msckf rotation items
+// MultiState layout in closed form (State.hpp:384-396): SO(3) block b sits at tangent 3 / 9 + 6b and storage
+// 3 / 9 + 7b (b = 0 / b >= 1); rot_count(b) = 13 / 25 + 12b sigma points differ from X_0 in that block, so the
+// prefix offsets of the flattened (block, sigma point) items are roff(b) = 6b^2 + 19b - 12 (b >= 1).
+__host__ __device__ __forceinline__ int msckf_toff(int b) { return b ? 9 + 6 * b : 3; }
+__host__ __device__ __forceinline__ int msckf_soff(int b) { return b ? 9 + 7 * b : 3; }
+__host__ __device__ __forceinline__ int msckf_roff(int b) { return b ? 6 * b * b + 19 * b - 12 : 0; }
+// item w -> (block, index in block) without a table: invert the quadratic, repair the float rounding
+__device__ __forceinline__ void msckf_rot_item(int w, int &b, int &i)
+{
+    int bb = 0;
+    if (w >= 13) {
+        bb = (int)((__builtin_sqrtf((float)(649 + 24 * w)) - 19.0f) * (1.0f / 12.0f));
+        if (msckf_roff(bb + 1) <= w) ++bb;
+        if (msckf_roff(bb) > w) --bb;
+    }
+    b = bb;
+    i = w - msckf_roff(bb);
+}
+// (mu [+] (delta +- L_j))_b [-] ref_b for item (b, i): all operands loaded up front (clamped addresses,
+// selects afterwards) so the LDS round trips overlap; an item exists only for j <= toff + 2
+__device__ __forceinline__ void rot_deviation(const double *mu, const double *ref, const double *Lp, const double *delta,
+                                              int N, int b, int i, double &dx, double &dy, double &dz)
+{
+    const int to = msckf_toff(b), so = msckf_soff(b);
+    const int j = (i > 0) ? ((i - 1) >> 1) : 0;
+    const double sgn = (i == 0) ? 0.0 : ((i & 1) ? 1.0 : -1.0);
+    const int jb = ((j * (2 * N - j + 1)) >> 1) - j;                  // pk(N, t, j) = jb + t
+    const bool in0 = j <= to, in1 = j <= to + 1;
+    const double l0 = Lp[in0 ? jb + to : 0], l1 = Lp[in1 ? jb + to + 1 : 0], l2 = Lp[jb + to + 2];
+    const double d0 = delta[to], d1 = delta[to + 1], d2 = delta[to + 2];
+    const Quat qm = ldq(mu + so), qr = ldq(ref + so);
+    const double v0 = d0 + sgn * (in0 ? l0 : 0.0), v1 = d1 + sgn * (in1 ? l1 : 0.0), v2 = d2 + sgn * l2;
+    so3_boxminus(qmul(qm, so3_exp(v0, v1, v2)), qr, dx, dy, dz);
 }
 
 // ------------------------------------------------------------------ register-resident Cholesky
@@ -568,6 +607,39 @@ __device__ __forceinline__ void measure_item(const KArgs &a, const Lay &L, const
         Zrow[3 * f + 2] = oz + (dk[2] - di[2]);
     }
 }
+// SLK_MM_FEATURE_PROJ with every operand loaded up front (clamped addresses, selects afterwards)
+__device__ __forceinline__ int feature_count(const Lay &L, const double *mp, int f, int S)
+{
+    int tp, sp, b;
+    pose_of(L, (int)mp[4 * f + 3], tp, sp, b);
+    const int c = 2 * (tp + 6) + 1;
+    return c < S ? c : S;
+}
+__device__ __forceinline__ void feature_proj_item(const Lay &L, const double *mp, const double *mu, const double *Lp,
+                                                  int i, int f, double *Zrow)
+{
+    const int n = L.N;
+    int tp, sp, b;
+    pose_of(L, (int)mp[4 * f + 3], tp, sp, b);
+    const int j = (i > 0) ? ((i - 1) >> 1) : 0;
+    const double sgn = (i == 0) ? 0.0 : ((i & 1) ? 1.0 : -1.0);
+    const int jb = ((j * (2 * n - j + 1)) >> 1) - j;                  // pk(n, t, j) = jb + t
+    double l[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) l[c] = Lp[(j <= tp + c) ? jb + tp + c : 0];
+    double x[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) x[c] = mu[sp + c];
+    const double fx = mp[4 * f], fy = mp[4 * f + 1], fz = mp[4 * f + 2];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) l[c] = sgn * ((j <= tp + c) ? l[c] : 0.0);
+    const double px = x[0] + l[0], py = x[1] + l[1], pz = x[2] + l[2];
+    const Quat q = qmul(Quat{x[3], x[4], x[5], x[6]}, so3_exp(l[3], l[4], l[5]));
+    double lx, ly, lz;
+    qrot(qconj(q), fx - px, fy - py, fz - pz, lx, ly, lz);
+    Zrow[2 * f] = lx / lz;
+    Zrow[2 * f + 1] = ly / lz;
+}
 __host__ __device__ __forceinline__ int measure_features(int mm, int m)
 {
     return mm == SLK_MM_FEATURE_PROJ ? m / 2 : (mm == SLK_MM_POSE_POSITION ? 1 : m / 3);
@@ -590,9 +662,30 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
         for (int e = tid; e < S * m; e += NTHREADS) Z[e] = Ze[e];
     } else {
         int nf = measure_features(a.mm, m);
-        for (int e = tid; e < S * nf; e += NTHREADS) {
-            int f = e % nf, i = e / nf;
-            measure_item(a, L, mp, mu, Lp, i, f, Z + i * m);
+        if (a.mm == SLK_MM_FEATURE_PROJ) {
+            // a feature seen from pose c depends on that pose's 6 tangent rows only; L is lower triangular, so
+            // only the sigma points of columns j <= tp + 5 differ from X_0 there: evaluate those items
+            // (flattened over the features), the rest of the feature's rows repeat Z_0
+            int total = 0;
+            for (int g = 0; g < nf; ++g) total += feature_count(L, mp, g, S);
+            for (int e = tid; e < total; e += NTHREADS) {
+                int f = 0, base = 0, run = 0;
+                for (int g = 0; g < nf; ++g) {
+                    if (e >= run) { f = g; base = run; }
+                    run += feature_count(L, mp, g, S);
+                }
+                feature_proj_item(L, mp, mu, Lp, e - base, f, Z + (e - base) * m);
+            }
+            __syncthreads();
+            for (int e = tid; e < S * nf; e += NTHREADS) {
+                int f = e % nf, i = e / nf;
+                if (i >= feature_count(L, mp, f, S)) { Z[i * m + 2 * f] = Z[2 * f]; Z[i * m + 2 * f + 1] = Z[2 * f + 1]; }
+            }
+        } else {
+            for (int e = tid; e < S * nf; e += NTHREADS) {
+                int f = e % nf, i = e / nf;
+                measure_item(a, L, mp, mu, Lp, i, f, Z + i * m);
+            }
         }
     }
     // rotation columns of L longer than pi make log(exp(v)) wrap (MTK log uses atan): flag them
@@ -602,7 +695,7 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
         if (v0 * v0 + v1 * v1 + v2 * v2 >= 9.869604401089358) *flag = 1;
     }
     __syncthreads();
-    SLK_STAMP(4);
+    SLK_STAMP_NR(4);
     // mean_z (:234), innovation (:236); DZ
     for (int r = tid / 32; r < m; r += NTHREADS / 32) {
         double sum = group_sum<32>(tid & 31, S, [&](int i) { return Z[i * m + r]; });
@@ -617,7 +710,7 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
         DZ[e] = Z[(2 * j + 1) * m + r] - Z[(2 * j + 2) * m + r];
     }
     __syncthreads();
-    SLK_STAMP(5);
+    SLK_STAMP_NR(5);
     // S = cov(Z) + R (:238), covXZ (:239 -> :635-657).  X_i [-] mu = +-L.col(j) (and 0 for X_0):
     // covXZ = 1/2 L * (Z_{2j+1} - Z_{2j+2})_j ; exact while every rotation column is shorter than pi.
     // Both are small GEMMs and run on the matrix cores: covXZ row tile I = L[16I.., :] * DZ (only the
@@ -670,7 +763,7 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
             Pxz[e] = 0.5 * sum;
         }
     }
-    SLK_STAMP(16);
+    SLK_STAMP_NR(16);
     // S: lower tiles (a >= b) of the m x m matrix
     for (int e = wave; e < ntm * (ntm + 1) / 2; e += NW) {      // wave 0 has the shortest covXZ tile
         int ta = 0;
@@ -703,9 +796,9 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
             }
         }
     }
-    SLK_STAMP(17);
+    SLK_STAMP_NR(17);
     __syncthreads();
-    SLK_STAMP(18);
+    SLK_STAMP_NR(18);
 }
 
 // ------------------------------------------------------------------ 12-DOF predict phase
@@ -911,7 +1004,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
     constexpr int SDN = (16 * NT + GD - 1) / GD;          // Cholesky register slots per dimension
     constexpr int SDM = (MAXM + GD - 1) / GD;
     const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const Lay L = a.lay;
+    Lay L = a.lay;
+    L.kind = SLK_MSCKF;                                    // this kernel is the Msckf step: fold the layout branches
     const int N = L.N, Nq = L.Nq, m = a.m, nso3 = L.nso3;
     const Carve cv = carve_step(L, m, NT, BIG);
     const int S = cv.S, LDD = cv.LDD;
@@ -1214,34 +1308,28 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
                         for (;;) {                                        // :507-516, then one pass against the final mean (:584)
                             // rotation blocks of X_i [-] ref, only the sigma points whose block differs from X_0's
                             for (int w = tid; w < W; w += NTHREADS) {
-                                int b = 0;
-                                for (int c = 1; c < nso3; ++c) b += (w >= roff[c]) ? 1 : 0;
-                                int i = w - roff[b];
-                                Quat q = sigma_quat(L, mu, Lp, delta, b, sig_of(i));
+                                int b, i;
+                                msckf_rot_item(w, b, i);
                                 double dx, dy, dz;
-                                so3_boxminus(q, ldq(ref + so3_soff(L, b)), dx, dy, dz);
+                                rot_deviation(mu, ref, Lp, delta, N, b, i, dx, dy, dz);
                                 DR[3 * w] = dx; DR[3 * w + 1] = dy; DR[3 * w + 2] = dz;
                             }
                             __syncthreads();
                             if (final_pass) break;
-                            // mean_delta = sum_i (X_i [-] ref) / S, 4 lanes per tangent row
-                            for (int t = tid / 4; t < N; t += NTHREADS / 4) {
-                                int blk = 0, comp = 0, s = t2s(L, t, blk, comp), sub = tid & 3;
-                                double sum;
-                                if (s >= 0) {
-                                    double m0 = mu[s], r0 = ref[s], dl = delta[t];
-                                    sum = group_sum<4>(sub, t + 1, [&](int j) {
-                                        double l = Lp[pk(N, t, j)];
-                                        return ((m0 + (dl + l)) - r0) + ((m0 + (dl - l)) - r0);
-                                    });
-                                    sum += (double)(S - 2 * (t + 1)) * ((m0 + dl) - r0);
-                                } else {
-                                    int cnt = roff[blk + 1] - roff[blk];
-                                    const double *row = DR + 3 * roff[blk] + comp;
-                                    sum = group_sum<4>(sub, cnt, [&](int i) { return row[3 * i]; });
-                                    sum += (double)(S - cnt) * row[0];
-                                }
-                                if (sub == 0) md[t] = sum / (double)S;
+                            // mean_delta = sum_i (X_i [-] ref) / S.  Vector rows: the +-L_j terms of the pairs
+                            // cancel, every sigma point contributes (mu + delta) - ref.  Rotation rows: 8 lanes
+                            // per row over the stored deviations, the other S - cnt points equal X_0's.
+                            for (int t = tid; t < N; t += NTHREADS) {
+                                int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
+                                if (s >= 0) md[t] = (mu[s] + delta[t]) - ref[s];
+                            }
+                            for (int e = tid / 8; e < 3 * nso3; e += NTHREADS / 8) {
+                                const int blk = e / 3, comp = e - 3 * blk, sub = tid & 7;
+                                const int r0 = msckf_roff(blk), cnt = msckf_roff(blk + 1) - r0;
+                                const double *row = DR + 3 * r0 + comp;
+                                double sum = group_sum<8>(sub, cnt, [&](int i) { return row[3 * i]; });
+                                sum += (double)(S - cnt) * row[0];
+                                if (sub == 0) md[msckf_toff(blk) + comp] = sum / (double)S;
                             }
                             __syncthreads();
                             double n2 = group_sum<64>(lane, N, [&](int t) { return md[t] * md[t]; });
@@ -1251,7 +1339,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
                                 if (s >= 0) ref[s] = ref[s] + md[t];
                             }
                             for (int b = tid; b < nso3; b += NTHREADS) {
-                                int to = so3_toff(L, b), so = so3_soff(L, b);
+                                int to = msckf_toff(b), so = msckf_soff(b);
                                 stq(ref + so, qmul(ldq(ref + so), so3_exp(md[to], md[to + 1], md[to + 2])));
                             }
                             __syncthreads();
