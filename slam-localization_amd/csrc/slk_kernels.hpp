@@ -190,7 +190,7 @@ __device__ __forceinline__ void msckf_rot_item(int w, int &b, int &i)
 {
     int bb = 0;
     if (w >= 13) {
-        bb = (int)((__builtin_sqrtf((float)(649 + 24 * w)) - 19.0f) * (1.0f / 12.0f));
+        bb = (int)((__builtin_amdgcn_sqrtf((float)(649 + 24 * w)) - 19.0f) * (1.0f / 12.0f));   // raw v_sqrt_f32, repaired below
         if (msckf_roff(bb + 1) <= w) ++bb;
         if (msckf_roff(bb) > w) --bb;
     }
@@ -1400,7 +1400,112 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
                                 }
                             }
                         };
-                        if (a.rebuild_prec == 0) {
+                        bool rebuilt = false;
+                        if constexpr (NT <= 4) {
+                            if (a.rebuild_prec == 0) {
+                                // ---- K-split rebuild: every wave owns ALL lower tiles for its share of the sigma
+                                // points (k-steps dealt round-robin), builds its A/B fragments straight from the
+                                // packed factor / the rotation deviations -- no panel staging, no barrier, no
+                                // fragment computed twice -- and the partial tiles are summed through LDS, which
+                                // also lets both triangles go out as contiguous 128-byte rows.
+                                constexpr int NTL = CholM<NT>::NTL;
+                                d4 acc[NTL];
+#pragma unroll
+                                for (int q = 0; q < NTL; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+                                const int c16 = lane & 15, g4 = lane >> 4;
+                                // Row t = 16 I + c16 of D, per lane and tile row, in ONE branch-free form
+                                //   D(t, i) = (qm + (qd + f * smem[bas + (c ? y : 0)])) - qr
+                                // vector row : bas = factor, c = j < t + 1, y = pk(N, t, j), f = c ? sgn : 0
+                                // rotation   : bas = its deviations, c = i < count, y = 3 i, f = 1, qm = qd = qr = 0
+                                // padding    : a vector row with threshold 0 and zero constants
+                                bool isv[NT];
+                                int bas[NT], thr[NT];
+                                double qm[NT], qd[NT], qr[NT];
+                                const int LpOff = (int)(Lp - smem), DROff = (int)(DR - smem);
+#pragma unroll
+                                for (int I = 0; I < NT; ++I) {
+                                    int t = 16 * I + c16, blk = 0, comp = 0;
+                                    isv[I] = true; bas[I] = LpOff; thr[I] = 0; qm[I] = 0.0; qd[I] = 0.0; qr[I] = 0.0;
+                                    if (t < N) {
+                                        int s = t2s(L, t, blk, comp);
+                                        if (s >= 0) { thr[I] = t + 1; qm[I] = mu[s]; qd[I] = delta[t]; qr[I] = ref[s]; }
+                                        else {
+                                            isv[I] = false;
+                                            bas[I] = DROff + 3 * msckf_roff(blk) + comp;
+                                            thr[I] = msckf_roff(blk + 1) - msckf_roff(blk);
+                                        }
+                                    }
+                                }
+                                const int nks = (S + 3) >> 2;
+                                for (int ks = wave; ks < nks; ks += NW) {
+                                    const int i = 4 * ks + g4;
+                                    const bool valid = i < S;
+                                    const int j = (i > 0) ? ((i - 1) >> 1) : 0;
+                                    const double sgn = (i == 0) ? 0.0 : ((i & 1) ? 1.0 : -1.0);
+                                    const int jbc = ((j * (2 * N - j + 1)) >> 1) - j + c16;   // pk(N, t, j) = jbc + 16 I
+                                    const int i3 = 3 * i;
+                                    double frag[NT];
+#pragma unroll
+                                    for (int I = 0; I < NT; ++I) {
+                                        const bool c = (isv[I] ? j : i) < thr[I];
+                                        const int y = isv[I] ? jbc + 16 * I : i3;
+                                        const double l = smem[bas[I] + (c ? y : 0)];
+                                        const double f = isv[I] ? (c ? sgn : 0.0) : 1.0;
+                                        const double v = (qm[I] + (qd[I] + f * l)) - qr[I];
+                                        frag[I] = valid ? v : 0.0;
+                                    }
+#pragma unroll
+                                    for (int I = 0; I < NT; ++I)
+#pragma unroll
+                                        for (int J = 0; J <= I; ++J)
+                                            acc[tile_idx(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[I], frag[J], acc[tile_idx(I, J)], 0, 0, 0);
+                                }
+                                __syncthreads();                     // factor, deviations and vectors are dead from here
+                                SLK_STAMP(14);
+                                constexpr int TS = 16 * 17;          // padded 16x16 tile, [col][row]
+                                int TR = cv.total / (NW * TS);
+                                if (TR > NTL) TR = NTL;
+                                double *red = smem;
+                                const int ea = tid & 15, eb = (tid >> 4) & 15;
+                                for (int T0 = 0; T0 < NTL; T0 += TR) {
+#pragma unroll
+                                    for (int T = 0; T < NTL; ++T)
+                                        if (T >= T0 && T < T0 + TR) {
+                                            double *dst = red + (wave * TR + (T - T0)) * TS + c16 * 17 + g4;
+#pragma unroll
+                                            for (int q = 0; q < 4; ++q) dst[4 * q] = acc[T][q];
+                                        }
+                                    __syncthreads();
+                                    const int ntl = (NTL - T0 < TR) ? NTL - T0 : TR;
+                                    // 256 threads per tile (the 64-thread kernels take four strides); tile index uniform
+                                    for (int Tl = 0; Tl < ntl; ++Tl) {
+                                        const int T = T0 + Tl;
+                                        const int I = (T >= 1) + (T >= 3) + (T >= 6), J = T - I * (I + 1) / 2;
+                                        const double *src = red + Tl * TS;
+                                        for (int e2 = eb; e2 < 16; e2 += NTHREADS / 16) {
+                                            {   // lower triangle: consecutive lanes = consecutive rows of one column
+                                                double sum = 0.0;
+#pragma unroll
+                                                for (int w = 0; w < NW; ++w) sum += src[w * TR * TS + e2 * 17 + ea];
+                                                const int row = 16 * I + ea, col = 16 * J + e2;
+                                                if (row < N && col < N) gP[row + (size_t)col * N] = 0.5 * sum;
+                                            }
+                                            if (I != J) {   // mirrored copy, again contiguous in the fast index
+                                                double sum = 0.0;
+#pragma unroll
+                                                for (int w = 0; w < NW; ++w) sum += src[w * TR * TS + ea * 17 + e2];
+                                                const int row = 16 * I + e2, col = 16 * J + ea;
+                                                if (row < N && col < N) gP[col + (size_t)row * N] = 0.5 * sum;
+                                            }
+                                        }
+                                    }
+                                    __syncthreads();
+                                }
+                                rebuilt = true;
+                            }
+                        }
+                        if (rebuilt) {
+                        } else if (a.rebuild_prec == 0) {
                         for (int pass = 0; pass < TilePlan<NT, NW>::PASSES; ++pass) {
                             d4 acc[TPW];
 #pragma unroll
