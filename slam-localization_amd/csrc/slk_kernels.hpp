@@ -652,7 +652,8 @@ __host__ __device__ __forceinline__ int measure_features(int mm, int m)
 template <int NTHREADS>
 __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L, int bidx, int tid, const double *mu,
                                                     const double *Lp, double *Z, double *DZ, double *Pxz,
-                                                    double *Sm, double *zbar, double *innov, int *flag)
+                                                    double *Sm, double *zbar, double *innov, int *flag,
+                                                    double *red = nullptr, int red_cap = 0)
 {
     const int N = L.N, m = a.m, S = 2 * N + 1, nso3 = L.nso3;
     const double *mp = a.mp ? a.mp + (size_t)bidx * a.mp_stride : nullptr;
@@ -764,6 +765,44 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
         }
     }
     SLK_STAMP_NR(16);
+    if (NW > 1 && ntm == 1 && red && NW * m * m <= red_cap) {
+        // one S tile (m <= 16): the 2N+1 sigma points are split over the waves (32 per trip), the
+        // partial m x m blocks meet in `red` (scratch of NW * m * m doubles)
+        const double za = (fc < m) ? zbar[fc] : 0.0;
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+        for (int k0 = 32 * wave; k0 < S; k0 += 32 * NW) {
+            double af[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = k0 + 4 * u + fg;
+                const bool ok = i < S && fc < m;
+                const double av = Z[ok ? i * m + fc : 0];
+                af[u] = ok ? av - za : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], af[u], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u + 1], af[u + 1], acc1, 0, 0, 0);
+            }
+        }
+        acc0 = acc0 + acc1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int orow = fg + 4 * r;
+            if (orow < m && fc < m) red[wave * m * m + fc * m + orow] = acc0[r];
+        }
+        __syncthreads();
+        for (int e = tid; e < m * m; e += NTHREADS) {
+            double sum = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += red[w * m * m + e];
+            Sm[e] = 0.5 * sum + R[e];
+        }
+        SLK_STAMP_NR(17);
+        __syncthreads();
+        SLK_STAMP_NR(18);
+        return;
+    }
     // S: lower tiles (a >= b) of the m x m matrix
     for (int e = wave; e < ntm * (ntm + 1) / 2; e += NW) {      // wave 0 has the shortest covXZ tile
         int ta = 0;
@@ -1108,7 +1147,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
             double *zbar = G + round_up(m * (2 * m + 1), 2);
             double *innov = zbar + round_up(m, 2);
             int *idx = ish;
-            measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lp, Z, DZ, Pxz, Sm, zbar, innov, &ish[42]);
+            measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lp, Z, DZ, Pxz, Sm, zbar, innov, &ish[42], K, N * m);
             SLK_STAMP(6);
             // removeOutliers (:241 -> :723-754) incl. the shifted second erase (:741-744)
             if (tid == 0) {

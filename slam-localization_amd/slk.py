@@ -51,7 +51,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("SLK_HIP_LIB") or LIB_PATH      # SLK_HIP_LIB: A/B runs of experimental builds (tools/ab.sh)
     if not os.path.exists(p):
         raise SlkError(f"{p} not built: run `python slam-localization_amd/build.py` (needs hipcc)")
     lib = C.CDLL(p)
