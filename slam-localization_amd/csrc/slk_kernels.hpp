@@ -231,9 +231,7 @@ __device__ __forceinline__ void rsqrt_pivot(double d, double &sq, double &rs)
     double h = 0.5 * d;
     y = y * fma(-h * y, y, 1.5);
     y = y * fma(-h * y, y, 1.5);
-    double g = d * y;
-    g = fma(0.5 * y, fma(-g, g, d), g);     // sqrt(d) to ~1 ulp
-    sq = g;
+    sq = d * y;                             // sqrt(d): y is 1/sqrt(d) to about an ulp already
     rs = y;
 }
 
@@ -649,10 +647,11 @@ __host__ __device__ __forceinline__ int measure_features(int mm, int m)
 // Z = h(X) over the implicit sigma points of (mu, L), mean_z, innovation, S = 1/2 dZ dZ^T + R and
 // covXZ = 1/2 sum (X_i [-] mu)(Z_i - mean_z)^T  (Msckf.hpp:231-239, Usckf.hpp:277-283).
 // Lp = packed Cholesky factor.  *flag must be 0 on entry.
-template <int NTHREADS>
+template <int NTHREADS, class DiagFn>
 __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L, int bidx, int tid, const double *mu,
                                                     const double *Lp, double *Z, double *DZ, double *Pxz,
                                                     double *Sm, double *zbar, double *innov, int *flag,
+                                                    DiagFn pdiag /* diagonal of the covariance Lp factors */,
                                                     double *red = nullptr, int red_cap = 0)
 {
     const int N = L.N, m = a.m, S = 2 * N + 1, nso3 = L.nso3;
@@ -689,13 +688,25 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
             }
         }
     }
-    // rotation columns of L longer than pi make log(exp(v)) wrap (MTK log uses atan): flag them
-    for (int e = tid; e < N * nso3; e += NTHREADS) {
-        int j = e % N, b = e / N, t0 = so3_toff(L, b);
-        double v0 = Lz(Lp, N, t0, j), v1 = Lz(Lp, N, t0 + 1, j), v2 = Lz(Lp, N, t0 + 2, j);
-        if (v0 * v0 + v1 * v1 + v2 * v2 >= 9.869604401089358) *flag = 1;
+    // rotation columns of L longer than pi make log(exp(v)) wrap (MTK log uses atan): flag them.
+    // Cheap bound first: |L(rot rows of block b, j)|^2 <= sum over the block's three rows of |L(row, :)|^2
+    // = P(t0,t0) + P(t0+1,t0+1) + P(t0+2,t0+2); only if that reaches pi^2 the columns are looked at.
+    for (int b = tid; b < nso3; b += NTHREADS) {
+        int t0 = so3_toff(L, b);
+        if (pdiag(t0) + pdiag(t0 + 1) + pdiag(t0 + 2) >= 9.869604401089358) *flag = 2;
     }
     __syncthreads();
+    if (*flag == 2) {
+        __syncthreads();
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        for (int e = tid; e < N * nso3; e += NTHREADS) {
+            int j = e % N, b = e / N, t0 = so3_toff(L, b);
+            double v0 = Lz(Lp, N, t0, j), v1 = Lz(Lp, N, t0 + 1, j), v2 = Lz(Lp, N, t0 + 2, j);
+            if (v0 * v0 + v1 * v1 + v2 * v2 >= 9.869604401089358) *flag = 1;
+        }
+        __syncthreads();
+    }
     SLK_STAMP_NR(4);
     // mean_z (:234), innovation (:236); DZ
     for (int r = tid / 32; r < m; r += NTHREADS / 32) {
@@ -1147,7 +1158,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
             double *zbar = G + round_up(m * (2 * m + 1), 2);
             double *innov = zbar + round_up(m, 2);
             int *idx = ish;
-            measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lp, Z, DZ, Pxz, Sm, zbar, innov, &ish[42], K, N * m);
+            measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lp, Z, DZ, Pxz, Sm, zbar, innov, &ish[42],
+                                           [&](int t) { return Pin(t, t); }, K, N * m);
             SLK_STAMP(6);
             // removeOutliers (:241 -> :723-754) incl. the shifted second erase (:741-744)
             if (tid == 0) {

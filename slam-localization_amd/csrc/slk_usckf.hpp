@@ -166,7 +166,8 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
             double *innov = zbar + round_up(m, 2);
             double *wv = innov + round_up(m, 2);                 // Ls^-1 innovation
             double *dlt = wv + 2 * round_up(m, 2);
-            measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lm, Z, DZ, Pxz, Sm, zbar, innov, &ish[42]);
+            measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lm, Z, DZ, Pxz, Sm, zbar, innov, &ish[42],
+                                           [&](int t) { return P[t + t * lda]; });
             // S^-1 (:285-286): S = 1/2 dZ dZ^T + R is SPD for a valid R -> Cholesky, row-wise solves
             if (wave == 0) {
                 auto sel = [&](int i, int j) { return Sm[i + m * j]; };
