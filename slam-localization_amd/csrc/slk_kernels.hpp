@@ -353,7 +353,7 @@ __device__ __forceinline__ void cholm_load(d4 (&acc)[CholM<NT>::NTL], int n, int
                 double v;
                 if (row < n && col < n) v = (row >= col) ? init(row, col) : init(col, row);
                 else v = (row == col) ? 1.0 : 0.0;
-                acc[tile_idx(I, J)][r] = v;
+                acc[tile_idx(I, J)][r] = -v;          // the accumulators hold -A: the rank-4 updates ADD L L^T
             }
 }
 
@@ -369,7 +369,7 @@ __device__ __forceinline__ void cholm_downdate(d4 (&acc)[CholM<NT>::NTL], int n,
         for (int I = 0; I < NT; ++I) {
             int rho = 16 * I + c;
             bool ok = cc < kk && rho < n;
-            af[I] = ok ? -xel(rho, cc) : 0.0;
+            af[I] = ok ? xel(rho, cc) : 0.0;           // (-A) += X Y^T
             bf[I] = ok ? yel(rho, cc) : 0.0;
         }
 #pragma unroll
@@ -402,14 +402,14 @@ struct CholMCols {
                     wave_sync();
                     // 2. 4x4 pivot block (same values in every lane) and this lane's raw panel rows
                     const double *pb = colbuf + k0;
-                    const double p00 = pb[0], p10 = pb[1], p20 = pb[2], p30 = pb[3];
-                    const double p11 = pb[LDC + 1], p21 = pb[LDC + 2], p31 = pb[LDC + 3];
-                    const double p22 = pb[2 * LDC + 2], p32 = pb[2 * LDC + 3], p33 = pb[3 * LDC + 3];
+                    const double p00 = -pb[0], p10 = -pb[1], p20 = -pb[2], p30 = -pb[3];          // published values are -A
+                    const double p11 = -pb[LDC + 1], p21 = -pb[LDC + 2], p31 = -pb[LDC + 3];
+                    const double p22 = -pb[2 * LDC + 2], p32 = -pb[2 * LDC + 3], p33 = -pb[3 * LDC + 3];
                     double v[NT][4];
 #pragma unroll
                     for (int I = JK; I < NT; ++I)
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) v[I][b] = colbuf[b * LDC + 16 * I + c];
+                        for (int b = 0; b < 4; ++b) v[I][b] = -colbuf[b * LDC + 16 * I + c];
                     wave_sync();       // the next step's publish must not overtake these reads
                     double s0, r0, s1, r1, s2, r2, s3, r3;
                     if (!(p00 > 0.0)) { fail = k0; break; }
@@ -429,7 +429,7 @@ struct CholMCols {
                     // 3. forward substitution of the panel rows -> fragments = factor entries
                     const int kap = k0 + g;
                     const double sg = (g == 0) ? s0 : (g == 1) ? s1 : (g == 2) ? s2 : s3;
-                    double frag[NT], nfrag[NT];
+                    double frag[NT];
 #pragma unroll
                     for (int I = JK; I < NT; ++I) {
                         const double x0 = v[I][0] * r0;
@@ -441,7 +441,6 @@ struct CholMCols {
                         if (rho == kap) f = sg;
                         if (rho < kap) f = 0.0;           // strictly upper part of the pivot block / retired rows
                         frag[I] = f;
-                        nfrag[I] = -f;
                         if (rho >= kap && rho < n && kap < n) Lp[pk(n, rho, kap)] = f;
                     }
                     // 4. rank-4 update of the trailing tiles, tile column by tile column: the tiles the NEXT
@@ -450,7 +449,7 @@ struct CholMCols {
                     for (int J = JK; J < NT; ++J)
 #pragma unroll
                         for (int I = J; I < NT; ++I)
-                            acc[tile_idx(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(nfrag[I], frag[J], acc[tile_idx(I, J)], 0, 0, 0);
+                            acc[tile_idx(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[I], frag[J], acc[tile_idx(I, J)], 0, 0, 0);
                 }
             }
             CholMCols<NT, JK + 1>::run(acc, Lp, n, colbuf, lane, fail);

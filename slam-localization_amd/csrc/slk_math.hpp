@@ -37,15 +37,13 @@ __device__ __forceinline__ void qrot(const Quat &q, double vx, double vy, double
 // MTK cos_sinc_sqrt(x) = (cos(sqrt x), sin(sqrt x)/sqrt x).  Both are entire functions of x:
 //   cos(sqrt x) = sum (-x)^k/(2k)!,   sin(sqrt x)/sqrt x = sum (-x)^k/(2k+1)!
 // For x < 1/4 (rotation below 1 rad, the usual sigma-point spread) the series are summed directly to
-// below 1 ulp (10 terms, Horner) -- no sqrt, no division, no range reduction; MTK itself switches to
+// below 1 ulp (8 terms, Horner) -- no sqrt, no division, no range reduction; MTK itself switches to
 // this series for tiny x (3 terms below eps^(1/4)).  Larger arguments take the libm route.
 __device__ __forceinline__ void cos_sinc_sqrt(double x, double &c, double &s)
 {
     if (x < 0.25) {
         const double y = -x;                      // Horner in y = -x
-        double cc = 1.0 / 6402373705728000.0;     // 1/18!
-        cc = fma(cc, y, 1.0 / 20922789888000.0);  // 1/16!
-        cc = fma(cc, y, 1.0 / 87178291200.0);     // 1/14!
+        double cc = 1.0 / 87178291200.0;          // 1/14!  (x^8/16! < 8e-19 for x < 1/4: far below half an ulp of 1)
         cc = fma(cc, y, 1.0 / 479001600.0);       // 1/12!
         cc = fma(cc, y, 1.0 / 3628800.0);         // 1/10!
         cc = fma(cc, y, 1.0 / 40320.0);           // 1/8!
@@ -53,9 +51,7 @@ __device__ __forceinline__ void cos_sinc_sqrt(double x, double &c, double &s)
         cc = fma(cc, y, 1.0 / 24.0);              // 1/4!
         cc = fma(cc, y, 0.5);                     // 1/2!
         cc = fma(cc, y, 1.0);
-        double ss = 1.0 / 121645100408832000.0;   // 1/19!
-        ss = fma(ss, y, 1.0 / 355687428096000.0); // 1/17!
-        ss = fma(ss, y, 1.0 / 1307674368000.0);   // 1/15!
+        double ss = 1.0 / 1307674368000.0;        // 1/15!  (x^8/17! < 5e-20)
         ss = fma(ss, y, 1.0 / 6227020800.0);      // 1/13!
         ss = fma(ss, y, 1.0 / 39916800.0);        // 1/11!
         ss = fma(ss, y, 1.0 / 362880.0);          // 1/9!
@@ -83,7 +79,7 @@ __device__ __forceinline__ Quat so3_exp(double vx, double vy, double vz)
 
 // MTK::SO3::log: 2 atan(|vec|/w)/|vec| * vec (|vec| clamped to 1e-11).  With u = |vec|/w the factor is
 // 2/w * atan(u)/u and atan(u)/u = sum (-u^2)^k/(2k+1): for u^2 < 1/16 (rotation below ~28 deg) the
-// series is summed directly (15 terms, < 1 ulp) -- one reciprocal instead of sqrt + 2 divisions + atan.
+// series is summed directly (13 terms, < 1 ulp) -- one reciprocal instead of sqrt + 2 divisions + atan.
 __device__ __forceinline__ void so3_log(const Quat &q, double &vx, double &vy, double &vz)
 {
     const double n2 = q.x * q.x + q.y * q.y + q.z * q.z;
@@ -92,9 +88,7 @@ __device__ __forceinline__ void so3_log(const Quat &q, double &vx, double &vy, d
     if (q.w > 0.0 && n2 * 16.0 < w2) {
         const double rw = 1.0 / q.w;
         const double y = -(n2 * rw * rw);
-        double f = 1.0 / 29.0;
-        f = fma(f, y, 1.0 / 27.0);
-        f = fma(f, y, 1.0 / 25.0);
+        double f = 1.0 / 25.0;                    // (1/16)^13 / 27 < 9e-18: below a tenth of an ulp
         f = fma(f, y, 1.0 / 23.0);
         f = fma(f, y, 1.0 / 21.0);
         f = fma(f, y, 1.0 / 19.0);
