@@ -44,6 +44,8 @@ struct slk_filter {
     unsigned *d_outliers;
     Stage st_u, st_Q, st_mp, st_z, st_R, st_X, st_Z, st_tmpP, st_tmpM;
     Stage ws_L, ws_DR;            // large-state workspaces (N > 96), allocated on first use
+    unsigned long long *d_rtab = nullptr;   // Msckf rotation-item descriptors of the current layout
+    int rtab_k = -1;
     hipEvent_t ev0, ev1;
     int rebuild_prec = 0;
 };
@@ -137,6 +139,7 @@ void slk_destroy(slk_filter *f)
     Stage *st[] = {&f->st_u, &f->st_Q, &f->st_mp, &f->st_z, &f->st_R, &f->st_X, &f->st_Z, &f->st_tmpP, &f->st_tmpM,
                    &f->ws_L, &f->ws_DR};
     for (Stage *s : st) if (s->p) (void)hipFree(s->p);
+    if (f->d_rtab) (void)hipFree(f->d_rtab);
     if (f->d_mean) (void)hipFree(f->d_mean);
     if (f->d_P) (void)hipFree(f->d_P);
     if (f->d_status) (void)hipFree(f->d_status);
@@ -186,6 +189,17 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
     KArgs a = a0;
     constexpr bool BIG = NT > 6;
     Carve cv = carve_step(a.lay, a.m, NT, BIG);
+    if (f->rtab_k != a.lay.k) {                 // layout changed (first launch, slk_msckf_resize): new descriptor table
+        std::vector<unsigned long long> tab((size_t)cv.W);
+        for (int w = 0; w < cv.W; ++w) tab[w] = rot_item_descriptor(a.lay.N, w);
+        if (f->d_rtab) HIPCHECK(hipFree(f->d_rtab));
+        f->d_rtab = nullptr; f->rtab_k = -1;
+        HIPCHECK(hipMalloc(&f->d_rtab, tab.size() * sizeof(unsigned long long)));
+        HIPCHECK(hipMemcpyAsync(f->d_rtab, tab.data(), tab.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, f->stream));
+        HIPCHECK(hipStreamSynchronize(f->stream));
+        f->rtab_k = a.lay.k;
+    }
+    a.rtab = f->d_rtab;
     if (BIG) {
         int rc = stage_reserve(f, f->ws_L, (size_t)a.B * pk_size(a.lay.N));
         if (rc) return rc;

@@ -36,6 +36,7 @@ struct KArgs {
     int emit; double *Xout;
     int rebuild_prec;     // covariance rebuild arithmetic: 0 = fp64 (parity path), 1 = fp32 MFMA, 2 = bf16 inputs / fp32 accumulate
     double *wsL, *wsDR;   // global workspaces of the large-state path (N > 96): packed factor, rotation deviations
+    const unsigned long long *rtab;   // Msckf: descriptors of the rotation items (layout only, built by the host)
     long long *dbg;   // phase stamps, diagnostic builds (-DSLK_STAMPS) only; always null in the product
     int stop;         // diagnostic builds: leave the kernel after this stamp (per-phase instruction counts)
 };
@@ -196,6 +197,35 @@ __device__ __forceinline__ void msckf_rot_item(int w, int &b, int &i)
     }
     b = bb;
     i = w - msckf_roff(bb);
+}
+// The (block, sigma point) -> addresses / signs arithmetic depends on the layout only: the host tabulates it
+// once per handle (rot_item_descriptor), the kernels unpack one 64-bit word per item.
+//   bits 0-15 index of L(toff+2, j) in the packed factor, 16 / 17 "j <= toff" / "j <= toff+1",
+//   18-19 sign (0: X_0, 1: +L_j, 2: -L_j), 20-27 toff, 28-37 soff
+__host__ __device__ inline unsigned long long rot_item_descriptor(int N, int w)
+{
+    int b = 0;
+    while (msckf_roff(b + 1) <= w) ++b;
+    const int i = w - msckf_roff(b), to = msckf_toff(b), so = msckf_soff(b);
+    const int j = (i > 0) ? ((i - 1) >> 1) : 0;
+    const unsigned long long a2 = (unsigned long long)(pk(N, to + 2, j));
+    const unsigned long long sc = (i == 0) ? 0 : ((i & 1) ? 1 : 2);
+    return a2 | ((unsigned long long)(j <= to) << 16) | ((unsigned long long)(j <= to + 1) << 17) | (sc << 18)
+           | ((unsigned long long)to << 20) | ((unsigned long long)so << 28);
+}
+__device__ __forceinline__ void rot_deviation_desc(unsigned long long d, const double *mu, const double *ref, const double *Lp,
+                                                   const double *delta, double &dx, double &dy, double &dz)
+{
+    const unsigned lo = (unsigned)d;
+    const int a2 = lo & 0xffff, to = (lo >> 20) & 0xff, so = (int)((d >> 28) & 0x3ff);
+    const bool in0 = lo & (1u << 16), in1 = lo & (1u << 17);
+    const unsigned sc = (lo >> 18) & 3;
+    const double sgn = (sc == 1) ? 1.0 : ((sc == 2) ? -1.0 : 0.0);
+    const double l0 = Lp[in0 ? a2 - 2 : 0], l1 = Lp[in1 ? a2 - 1 : 0], l2 = Lp[a2];
+    const double d0 = delta[to], d1 = delta[to + 1], d2 = delta[to + 2];
+    const Quat qm = ldq(mu + so), qr = ldq(ref + so);
+    const double v0 = d0 + sgn * (in0 ? l0 : 0.0), v1 = d1 + sgn * (in1 ? l1 : 0.0), v2 = d2 + sgn * l2;
+    so3_boxminus(qmul(qm, so3_exp(v0, v1, v2)), qr, dx, dy, dz);
 }
 // (mu [+] (delta +- L_j))_b [-] ref_b for item (b, i): all operands loaded up front (clamped addresses,
 // selects afterwards) so the LDS round trips overlap; an item exists only for j <= toff + 2
@@ -1358,10 +1388,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
                         for (;;) {                                        // :507-516, then one pass against the final mean (:584)
                             // rotation blocks of X_i [-] ref, only the sigma points whose block differs from X_0's
                             for (int w = tid; w < W; w += NTHREADS) {
-                                int b, i;
-                                msckf_rot_item(w, b, i);
                                 double dx, dy, dz;
-                                rot_deviation(mu, ref, Lp, delta, N, b, i, dx, dy, dz);
+                                rot_deviation_desc(a.rtab[w], mu, ref, Lp, delta, dx, dy, dz);
                                 DR[3 * w] = dx; DR[3 * w + 1] = dy; DR[3 * w + 2] = dz;
                             }
                             __syncthreads();

@@ -26,8 +26,10 @@ for k in acc:
         print(f"   {c:28s} per-dispatch {v / n[(k, c)]:.4g}")
 PY
 }
-run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU 2>&1 | tee gpurun_out/pmc_${TAG}_sq1.txt
-run sq2 SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM 2>&1 | tee gpurun_out/pmc_${TAG}_sq2.txt
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU 2>&1 | tee gpurun_out/pmc_${TAG}_sq1.txt
+run sq2 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE 2>&1 | tee gpurun_out/pmc_${TAG}_sq2.txt
+run sq3 SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT 2>&1 | tee gpurun_out/pmc_${TAG}_sq3.txt
+run sq4 SQ_INSTS_BRANCH SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU 2>&1 | tee gpurun_out/pmc_${TAG}_sq4.txt
 run tcc1 FETCH_SIZE 2>&1 | tee gpurun_out/pmc_${TAG}_fetch.txt
 run tcc2 WRITE_SIZE 2>&1 | tee gpurun_out/pmc_${TAG}_write.txt
 if [ "${2:-}" = "icache" ]; then
