@@ -92,6 +92,13 @@ namespace localization
             slk::check(slk_predict(h.get(), SLK_PM_CONST_VELOCITY, f.u, 0, Q.data(), 0, SLK_HOST), "slk_predict");
             mean_stale = cov_stale = true;
         }
+        /** dead reckoning fused into the prediction (src/core/DeadReckon.hpp:129-239 -> the delta-pose model) */
+        template <class Cov>
+        void predict(const slk::DeadReckonModel &f, const Cov &Q)
+        {
+            slk::check(slk_predict(h.get(), SLK_PM_DEAD_RECKON, f.u, 0, Q.data(), 0, SLK_HOST), "slk_predict");
+            mean_stale = cov_stale = true;
+        }
         /**@brief Filter prediction step with an arbitrary process model functor f: _SingleState -> _SingleState */
         template <typename _ProcessModel, class Cov>
         void predict(_ProcessModel f, const Cov &Q)

@@ -59,6 +59,16 @@ namespace slk
             for (int i = 0; i < 4; ++i) u[3 + i] = dq.coeffs()[i];
         }
     };
+    struct DeadReckonModel         /* src/core/DeadReckon.hpp:129-239 (delta pose from two velocity samples) feeding the delta-pose model */
+    {
+        double u[13];
+        DeadReckonModel(double dt, const Vec3 &velocity, const Vec3 &angular_velocity,
+                        const Vec3 &prev_velocity, const Vec3 &prev_angular_velocity)
+        {
+            u[0] = dt;
+            for (int i = 0; i < 3; ++i) { u[1 + i] = velocity[i]; u[4 + i] = angular_velocity[i]; u[7 + i] = prev_velocity[i]; u[10 + i] = prev_angular_velocity[i]; }
+        }
+    };
     /** Registered measurement models. */
     struct VoRelativeModel {};     /* test/UsckfUnitTest.cpp:62-86 */
     struct FeatureProjectionModel  /* m/2 landmarks seen as normalised image points from pose indices */
@@ -71,6 +81,7 @@ namespace slk
     template <class T> struct is_registered_process { enum { value = 0 }; };
     template <> struct is_registered_process<ConstVelocityModel> { enum { value = 1 }; };
     template <> struct is_registered_process<DeltaPoseModel> { enum { value = 1 }; };
+    template <> struct is_registered_process<DeadReckonModel> { enum { value = 1 }; };
 
     /** column-major copy of anything with data()/rows()/cols() */
     template <class M>

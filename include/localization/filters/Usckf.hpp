@@ -105,6 +105,12 @@ namespace localization
             slk::check(slk_predict(h.get(), SLK_PM_DELTA_POSE, f.u, 0, Q.data(), 0, SLK_HOST), "slk_predict");
             stale = true;
         }
+        template <class Cov>
+        void predict(const slk::DeadReckonModel &f, const Cov &Q)
+        {
+            slk::check(slk_predict(h.get(), SLK_PM_DEAD_RECKON, f.u, 0, Q.data(), 0, SLK_HOST), "slk_predict");
+            stale = true;
+        }
         /**@brief predict with an arbitrary process model functor (the reference's boost::bind form, UsckfUnitTest.cpp:246) */
         template <typename _ProcessModel, class Cov>
         void predict(_ProcessModel f, const Cov &Q)

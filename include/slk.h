@@ -70,7 +70,10 @@ enum { SLK_STATEK = 1, SLK_STATEK_L = 2, SLK_STATEK_I = 3 };
 enum {
     SLK_MODEL_EXTERNAL = 0,
     SLK_PM_CONST_VELOCITY = 1,  /* test/UsckfUnitTest.cpp:34-49; u = velocity[3] angular_velocity[3] dt  (7) */
-    SLK_PM_DELTA_POSE = 2       /* test/MsckfUnitTest.cpp:33-47; u = dpos[3] dquat[4] velocity[3] angular_velocity[3] (13) */
+    SLK_PM_DELTA_POSE = 2,      /* test/MsckfUnitTest.cpp:33-47; u = dpos[3] dquat[4] velocity[3] angular_velocity[3] (13) */
+    SLK_PM_DEAD_RECKON = 3      /* the step before predict fused in: DeadReckon::updatePose delta pose
+                                   (src/core/DeadReckon.hpp:129-239, updateAttitude :246-286) feeding the delta-pose model;
+                                   u = dt, current velocity[3] angular_velocity[3], previous velocity[3] angular_velocity[3] (13) */
 };
 
 /* Registered measurement models h: FullState -> R^m */
@@ -114,6 +117,12 @@ double *slk_cov_device_ptr(slk_filter *f);
  *      Q 12x12 (q_stride 0 = shared, else per-filter stride in doubles). ---- */
 int slk_predict(slk_filter *f, int model, const double *u, int u_stride,
                 const double *Q, int q_stride, int where);
+
+/* ---- DeadReckon::updatePose (src/core/DeadReckon.hpp:129-239), delta-pose part, for the whole batch:
+ *      u [B][u_stride] = dt v0[3] w0[3] v1[3] w1[3]  ->  delta [B][13] = dpos[3] dquat[4] velocity[3] angular_velocity[3],
+ *      which is the `u` of slk_predict(SLK_PM_DELTA_POSE).  The covariance part of the reference
+ *      (cov_position = C_vv dt^2, cov_orientation = C_ww dt^2, :167-176) is a scaling left to the caller. ---- */
+int slk_dead_reckon(slk_filter *f, const double *u, int u_stride, double *delta, int where);
 
 /* ---- update(z, h, R[, mt]): UKF update, Msckf.hpp:196-277 (chi-square gate per 2-row block
  *      + applyDelta re-draw) and Usckf.hpp:246-308 (whole-vector gate, direct boxplus).

@@ -112,6 +112,38 @@ def pm_delta_pose(x, dpos, dquat, velocity, angular_velocity):
     return y
 
 
+def _omega4(w):
+    """4x4 angular-velocity matrix acting on (w, x, y, z), as written in src/core/DeadReckon.hpp:259-267."""
+    return np.array([[0.0, -w[0], -w[1], -w[2]],
+                     [w[0], 0.0, w[2], -w[1]],
+                     [w[1], -w[2], 0.0, w[0]],
+                     [w[2], w[1], -w[0], 0.0]])
+
+
+def update_attitude(dt, w0, w1):
+    """DeadReckon::updateAttitude (src/core/DeadReckon.hpp:246-286) with the full 4x4 expression; returns (x,y,z,w)."""
+    w0, w1 = np.asarray(w0, float), np.asarray(w1, float)
+    om, old, eye = _omega4(w0), _omega4(w1), np.eye(4)
+    n2 = float(w0 @ w0)
+    M = (eye + 0.75 * om * dt - 0.25 * old * dt - (1.0 / 6.0) * n2 * dt ** 2 * eye
+         - (1.0 / 24.0) * om @ old * dt ** 2 - (1.0 / 48.0) * n2 * om * dt ** 3)
+    q = M @ np.array([1.0, 0.0, 0.0, 0.0])
+    q = q / np.linalg.norm(q)
+    return np.array([q[1], q[2], q[3], q[0]])
+
+
+def dead_reckon_delta(u):
+    """DeadReckon::updatePose delta pose (src/core/DeadReckon.hpp:129-239): u = dt v0 w0 v1 w1 -> dpos dquat v w."""
+    u = np.asarray(u, float)
+    dt, v0, w0, v1, w1 = u[0], u[1:4], u[4:7], u[7:10], u[10:13]
+    return np.concatenate([(dt / 2.0) * (v0 + v1), update_attitude(dt, w0, w1), v0, w0])
+
+
+def pm_dead_reckon(x, u):
+    d = dead_reckon_delta(u)
+    return pm_delta_pose(x, d[0:3], d[3:7], d[7:10], d[10:13])
+
+
 def mm_vo_relative(X, nfk):
     single = Manifold.single()
     d = single.minus(X[0:13], X[26:39])

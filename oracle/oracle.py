@@ -246,6 +246,24 @@ def pm_delta_pose(dpos, dquat, velocity, angular_velocity):
     return Model(fn_addr("slko_pm_delta_pose"), s, C.cast(C.pointer(s), C.c_void_p))
 
 
+def pm_dead_reckon(u):
+    """DeadReckon::updatePose delta (src/core/DeadReckon.hpp:129-239) feeding the delta-pose model; u = dt v0 w0 v1 w1."""
+    buf = (C.c_double * 13)(*[float(v) for v in u])
+    return Model(fn_addr("slko_pm_dead_reckon"), buf, C.cast(buf, C.c_void_p))
+
+
+def dead_reckon_delta(u):
+    """[..., 13] inputs -> [..., 13] delta poses (dpos3 dquat4 velocity3 angular_velocity3)."""
+    L = lib()
+    L.slko_dead_reckon_delta.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.slko_dead_reckon_delta.restype = None
+    uu = np.ascontiguousarray(np.asarray(u, dtype=np.float64).reshape(-1, 13))
+    out = np.zeros_like(uu)
+    for r in range(uu.shape[0]):
+        L.slko_dead_reckon_delta(uu[r].ctypes.data_as(C.POINTER(C.c_double)), out[r].ctypes.data_as(C.POINTER(C.c_double)))
+    return out.reshape(np.asarray(u).shape)
+
+
 def pm_python(fn):
     """Opaque host functor (the reference's boost::bind form): fn(x13 ndarray) -> y13 ndarray."""
     def tramp(xp, yp, _ctx):

@@ -439,6 +439,50 @@ void slko_pm_delta_pose(const double *x, double *y, void *ctx)
     for (int i = 0; i < 3; ++i) y[7 + i] = p->velocity[i];
 }
 
+/* src/core/DeadReckon.hpp:246-286 (updateAttitude): third-order quaternion integration of the angular
+ * velocity, constant angular acceleration between the previous (w1) and the current (w0) sample.
+ * The 4x4 expression of the reference acts on the identity quaternion (w,x,y,z) = (1,0,0,0): only its
+ * first column is ever used, written out here.  Result (x,y,z,w), normalised like Eigen::normalize. */
+void slko_update_attitude(double dt, const double w0[3], const double w1[3], double q[4])
+{
+    const double n2 = w0[0] * w0[0] + w0[1] * w0[1] + w0[2] * w0[2];
+    const double dot = w0[0] * w1[0] + w0[1] * w1[1] + w0[2] * w1[2];
+    const double cr[3] = { w0[1] * w1[2] - w0[2] * w1[1], w0[2] * w1[0] - w0[0] * w1[2], w0[0] * w1[1] - w0[1] * w1[0] };
+    const double dt2 = dt * dt, dt3 = dt2 * dt;
+    /* (omega4 * oldomega4) e0 = (-w0.w1, -(w0 x w1)) */
+    double qw = 1.0 - (1.0 / 6.0) * n2 * dt2 - (1.0 / 24.0) * (-dot) * dt2;
+    double qv[3];
+    for (int i = 0; i < 3; ++i)
+        qv[i] = 0.75 * w0[i] * dt - 0.25 * w1[i] * dt - (1.0 / 24.0) * (-cr[i]) * dt2 - (1.0 / 48.0) * n2 * w0[i] * dt3;
+    const double nrm = sqrt(qw * qw + qv[0] * qv[0] + qv[1] * qv[1] + qv[2] * qv[2]);
+    q[0] = qv[0] / nrm; q[1] = qv[1] / nrm; q[2] = qv[2] / nrm; q[3] = qw / nrm;
+}
+
+/* src/core/DeadReckon.hpp:129-239, the delta pose of updatePose(delta_t, cartesianVelocities, ...):
+ * u = dt, v0[3], w0[3] (current linear / angular velocity), v1[3], w1[3] (previous sample).
+ * delta = dpos[3] dquat[4] velocity[3] angular_velocity[3] = the input of the delta-pose process model. */
+void slko_dead_reckon_delta(const double u[13], double delta[13])
+{
+    const double dt = u[0];
+    for (int i = 0; i < 3; ++i) delta[i] = (dt / 2.0) * (u[1 + i] + u[7 + i]);      /* :148 */
+    slko_update_attitude(dt, u + 4, u + 10, delta + 3);                              /* :161 */
+    for (int i = 0; i < 3; ++i) delta[7 + i] = u[1 + i];                             /* :150 */
+    for (int i = 0; i < 3; ++i) delta[10 + i] = u[4 + i];                            /* :151 */
+}
+
+/* dead reckoning feeding the delta-pose process model (test/MsckfUnitTest.cpp:33-47); ctx = double[13] u */
+void slko_pm_dead_reckon(const double *x, double *y, void *ctx)
+{
+    double d[13];
+    slko_delta_pose p;
+    slko_dead_reckon_delta((const double *)ctx, d);
+    memcpy(p.dpos, d, 3 * sizeof(double));
+    memcpy(p.dquat, d + 3, 4 * sizeof(double));
+    memcpy(p.velocity, d + 7, 3 * sizeof(double));
+    memcpy(p.angular_velocity, d + 10, 3 * sizeof(double));
+    slko_pm_delta_pose(x, y, &p);
+}
+
 /* Eigen QuaternionBase::toRotationMatrix (used through Eigen::Affine3d(orient),
  * UsckfUnitTest.cpp:71). R is 3x3 column-major. */
 static void quat_to_matrix(const double q[4], double R[9])

@@ -82,6 +82,10 @@ typedef struct { double velocity[3], angular_velocity[3], dt; } slko_const_veloc
 typedef struct { double dpos[3], dquat[4], velocity[3], angular_velocity[3]; } slko_delta_pose; /* MsckfUnitTest.cpp:33-47 */
 void slko_pm_const_velocity(const double *x, double *y, void *ctx);
 void slko_pm_delta_pose(const double *x, double *y, void *ctx);
+/* dead reckoning (src/core/DeadReckon.hpp:129-239, :246-286): u = dt v0[3] w0[3] v1[3] w1[3] */
+void slko_update_attitude(double dt, const double w0[3], const double w1[3], double q[4]);
+void slko_dead_reckon_delta(const double u[13], double delta[13]);
+void slko_pm_dead_reckon(const double *x, double *y, void *ctx);   /* ctx = double[13] u */
 
 /* measurement models */
 void slko_mm_vo_relative(const slko_layout *lay, const double *X, int m, double *z, void *ctx); /* UsckfUnitTest.cpp:62-86 */

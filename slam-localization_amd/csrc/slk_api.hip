@@ -287,7 +287,7 @@ static void base_args(slk_filter *f, KArgs &a)
     a.rebuild_prec = f->rebuild_prec;
 }
 
-static int pm_inputs(int model) { return model == SLK_PM_CONST_VELOCITY ? 7 : (model == SLK_PM_DELTA_POSE ? 13 : 0); }
+static int pm_inputs(int model) { return model == SLK_PM_CONST_VELOCITY ? 7 : ((model == SLK_PM_DELTA_POSE || model == SLK_PM_DEAD_RECKON) ? 13 : 0); }
 static int mm_params(int model, int m)
 {
     return model == SLK_MM_FEATURE_PROJ ? (m / 2) * 4 : (model == SLK_MM_POSE_POSITION ? 1 : 0);
@@ -296,7 +296,7 @@ static int mm_params(int model, int m)
 static int fill_predict(slk_filter *f, KArgs &a, int model, const double *u, int u_stride,
                         const double *Q, int q_stride, int where)
 {
-    if (model != SLK_PM_CONST_VELOCITY && model != SLK_PM_DELTA_POSE) return SLK_E_INVALID;
+    if (model != SLK_PM_CONST_VELOCITY && model != SLK_PM_DELTA_POSE && model != SLK_PM_DEAD_RECKON) return SLK_E_INVALID;
     if (!u || !Q) return SLK_E_INVALID;
     int nu = pm_inputs(model);
     if (u_stride != 0 && u_stride < nu) return SLK_E_INVALID;
@@ -338,7 +338,39 @@ static int launch(slk_filter *f, const KArgs &a)
     return f->lay.kind == SLK_MSCKF ? launch_msckf(f, a) : launch_usckf(f, a);
 }
 
+// DeadReckon::updatePose delta poses of a batch (src/core/DeadReckon.hpp:129-239): one thread per filter
+__global__ void dead_reckon_kernel(int B, const double *u, int u_stride, double *delta)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double uu[13], d[13];
+    const double *src = u + (size_t)b * u_stride;
+    for (int i = 0; i < 13; ++i) uu[i] = src[i];
+    dead_reckon_delta(uu, d);
+    for (int i = 0; i < 13; ++i) delta[(size_t)b * 13 + i] = d[i];
+}
+
 extern "C" {
+
+int slk_dead_reckon(slk_filter *f, const double *u, int u_stride, double *delta, int where)
+{
+    if (!f || !u || !delta) return SLK_E_INVALID;
+    if (u_stride != 0 && u_stride < 13) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    const double *du = nullptr;
+    int rc = stage_in(f, f->st_u, u, u_stride ? (size_t)f->B * u_stride : (size_t)13, where, &du);
+    if (rc) return rc;
+    size_t n = (size_t)f->B * 13;
+    double *dd = delta;
+    if (where == SLK_HOST) { rc = stage_reserve(f, f->st_X, n); if (rc) return rc; dd = f->st_X.p; }
+    hipLaunchKernelGGL(dead_reckon_kernel, dim3((f->B + 255) / 256), dim3(256), 0, f->stream, f->B, du, u_stride, dd);
+    HIPCHECK(hipGetLastError());
+    if (where == SLK_HOST) {
+        HIPCHECK(hipMemcpyAsync(delta, dd, n * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+        HIPCHECK(hipStreamSynchronize(f->stream));
+    }
+    return SLK_OK;
+}
 
 int slk_predict(slk_filter *f, int model, const double *u, int u_stride, const double *Q, int q_stride, int where)
 {

@@ -138,11 +138,45 @@ __device__ __forceinline__ void state_boxminus(const double *a, const double *b,
     d[9] = a[10] - b[10]; d[10] = a[11] - b[11]; d[11] = a[12] - b[12];
 }
 
+// ---------------------------------------------------------------- dead reckoning
+// DeadReckon::updateAttitude (src/core/DeadReckon.hpp:246-286): third-order quaternion integration, constant angular
+// acceleration between the previous (w1) and the current (w0) sample.  The reference's 4x4 expression acts on the
+// identity quaternion, i.e. only its first column is used: omega4 e0 = (0, w), (omega4 oldomega4) e0 = (-w0.w1, -(w0 x w1)).
+__device__ __forceinline__ Quat update_attitude(double dt, const double *w0, const double *w1)
+{
+    const double n2 = w0[0] * w0[0] + w0[1] * w0[1] + w0[2] * w0[2];
+    const double dot = w0[0] * w1[0] + w0[1] * w1[1] + w0[2] * w1[2];
+    const double cx = w0[1] * w1[2] - w0[2] * w1[1], cy = w0[2] * w1[0] - w0[0] * w1[2], cz = w0[0] * w1[1] - w0[1] * w1[0];
+    const double dt2 = dt * dt, dt3 = dt2 * dt;
+    const double qw = 1.0 - (1.0 / 6.0) * n2 * dt2 + (1.0 / 24.0) * dot * dt2;
+    const double k = (1.0 / 48.0) * n2 * dt3;
+    const double qx = 0.75 * w0[0] * dt - 0.25 * w1[0] * dt + (1.0 / 24.0) * cx * dt2 - k * w0[0];
+    const double qy = 0.75 * w0[1] * dt - 0.25 * w1[1] * dt + (1.0 / 24.0) * cy * dt2 - k * w0[1];
+    const double qz = 0.75 * w0[2] * dt - 0.25 * w1[2] * dt + (1.0 / 24.0) * cz * dt2 - k * w0[2];
+    const double nrm = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+    return Quat{qx / nrm, qy / nrm, qz / nrm, qw / nrm};
+}
+// DeadReckon::updatePose delta pose (src/core/DeadReckon.hpp:129-239): u = dt v0[3] w0[3] v1[3] w1[3] ->
+// d = dpos[3] dquat[4] velocity[3] angular_velocity[3] (the input of the delta-pose process model)
+__device__ __forceinline__ void dead_reckon_delta(const double *u, double *d)
+{
+    const double dt = u[0];
+    for (int i = 0; i < 3; ++i) d[i] = (dt / 2.0) * (u[1 + i] + u[7 + i]);
+    stq(d + 3, update_attitude(dt, u + 4, u + 10));
+    for (int i = 0; i < 3; ++i) { d[7 + i] = u[1 + i]; d[10 + i] = u[4 + i]; }
+}
+
 // ---------------------------------------------------------------- registered process models
 // SLK_PM_CONST_VELOCITY: test/UsckfUnitTest.cpp:34-49;  u = v[3] w[3] dt
 // SLK_PM_DELTA_POSE:     test/MsckfUnitTest.cpp:33-47;  u = dpos[3] dquat[4] v[3] w[3]
+// SLK_PM_DEAD_RECKON:    src/core/DeadReckon.hpp:129-239 feeding the delta-pose model; u = dt v0[3] w0[3] v1[3] w1[3]
 __device__ __forceinline__ void process_model(int model, const double *u, const double *x, double *y)
 {
+    double dr[13];
+    if (model == 3) {           // SLK_PM_DEAD_RECKON: the delta pose comes from the velocity samples
+        dead_reckon_delta(u, dr);
+        u = dr;
+    }
     if (model == 1) {
         double dt = u[6];
         Quat rot = so3_exp(u[3] * dt, u[4] * dt, u[5] * dt);

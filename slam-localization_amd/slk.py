@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libslk_hip.so")
 MSCKF, USCKF = 1, 2
 HOST, DEVICE = 0, 1
 STATEK, STATEK_L, STATEK_I = 1, 2, 3
-MODEL_EXTERNAL, PM_CONST_VELOCITY, PM_DELTA_POSE = 0, 1, 2
+MODEL_EXTERNAL, PM_CONST_VELOCITY, PM_DELTA_POSE, PM_DEAD_RECKON = 0, 1, 2, 3
 MM_VO_RELATIVE, MM_FEATURE_PROJ, MM_POSE_POSITION = 1, 2, 3
 ST_LLT_FAIL, ST_MEAN_NOT_CONVERGED, ST_SINGULAR, ST_ALL_REJECTED = 1, 2, 4, 8
 E_INVALID, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = -1, -2, -3, -4, -5
@@ -30,7 +30,7 @@ EXPORTS = [
     "slk_step", "slk_predict_sigma_points", "slk_predict_from_sigma", "slk_update_sigma_points",
     "slk_update_from_sigma", "slk_usckf_cloning", "slk_usckf_set_measurement", "slk_msckf_resize",
     "slk_get_outliers", "slk_get_status", "slk_clear_status", "slk_sync", "slk_timer_start", "slk_timer_stop",
-    "slk_selftest_mfma", "slk_set_rebuild_precision",
+    "slk_selftest_mfma", "slk_set_rebuild_precision", "slk_dead_reckon",
 ]
 
 
@@ -69,6 +69,7 @@ def load_library(path=None):
     lib.slk_cov_device_ptr.argtypes = [vp]
     lib.slk_cov_device_ptr.restype = vp
     lib.slk_predict.argtypes = [vp, ip, vp, ip, vp, ip, ip]
+    lib.slk_dead_reckon.argtypes = [vp, vp, ip, vp, ip]
     lib.slk_update.argtypes = [vp, ip, vp, ip, vp, ip, vp, ip, ip, ip]
     lib.slk_step.argtypes = [vp, ip, vp, ip, vp, ip, ip, vp, ip, vp, ip, vp, ip, ip, ip]
     lib.slk_predict_sigma_points.argtypes = [vp, vp, ip]
@@ -280,6 +281,20 @@ class _FilterBatch:
         X = np.empty((self.B, 25, 13))
         _check(self._lib.slk_predict_sigma_points(self._h, X.ctypes.data, HOST), "slk_predict_sigma_points")
         return X
+
+    def dead_reckon(self, u):
+        """DeadReckon::updatePose delta poses (src/core/DeadReckon.hpp:129-239) for the batch: u = dt v0 w0 v1 w1
+        (shared row or [B, 13]) -> [B, 13] = dpos dquat velocity angular_velocity, the `u` of PM_DELTA_POSE.
+        numpy in -> numpy out; a torch device tensor in -> a torch device tensor out."""
+        ua = _rows(u, self.B, 13)
+        if ua.where == DEVICE:
+            import torch
+            out = torch.empty((self.B, 13), dtype=torch.float64, device=u.device)
+            _check(self._lib.slk_dead_reckon(self._h, ua.ptr, ua.stride, out.data_ptr(), DEVICE), "slk_dead_reckon")
+            return out
+        out = np.empty((self.B, 13))
+        _check(self._lib.slk_dead_reckon(self._h, ua.ptr, ua.stride, out.ctypes.data, HOST), "slk_dead_reckon")
+        return out
 
     def predict_functor(self, f, Q):
         """predict(f, Q) with an arbitrary Python callable f: state[13] -> state[13], applied on the host."""

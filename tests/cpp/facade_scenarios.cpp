@@ -6,6 +6,7 @@
 // Prints "name rows cols v0 v1 ..." lines (column-major) that tests/test_gpu_facade.py checks
 // against the golden fixtures.
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
 
 #include <localization/filters/Msckf.hpp>
@@ -136,9 +137,29 @@ static int usckf_scenario()
     return 0;
 }
 
-int main()
+// dead reckoning fused into predict (src/core/DeadReckon.hpp:129-239 -> the delta-pose model): the tag type
+// through the facade, input row 0 and 1 of tests/golden/dead_reckon.npz are passed on the command line by the test
+static void dead_reckon_scenario(const double *u)
+{
+    WMultiState statek_0;
+    statek_0.sensorsk.resize(1);
+    slk::Matrix Pk_0 = 0.025 * slk::Matrix::Identity(18, 18);
+    slk::Matrix cov_process = 0.01 * slk::Matrix::Identity(12, 12);
+    MultiStateFilter filter(statek_0, Pk_0);
+    filter.predict(slk::DeadReckonModel(u[0], slk::Vec3(u[1], u[2], u[3]), slk::Vec3(u[4], u[5], u[6]),
+                                        slk::Vec3(u[7], u[8], u[9]), slk::Vec3(u[10], u[11], u[12])), cov_process);
+    dump_mean("dead_reckon_mean", filter.muState(), 20);
+    dump("dead_reckon_P", filter.getPk());
+}
+
+int main(int argc, char **argv)
 {
     int st = 0;
+    if (argc == 14) {
+        double u[13];
+        for (int i = 0; i < 13; ++i) u[i] = std::atof(argv[1 + i]);
+        dead_reckon_scenario(u);
+    }
     for (int k : {0, 4, 8}) st |= msckf_scenario(k, false);
     st |= msckf_scenario(4, true);
     usckf_scenario();

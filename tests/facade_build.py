@@ -17,8 +17,8 @@ def build():
     return EXE
 
 
-def run():
-    out = subprocess.run([build()], capture_output=True, text=True, timeout=300)
+def run(args=()):
+    out = subprocess.run([build()] + [repr(float(a)) for a in args], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     res = {}
     for line in out.stdout.splitlines():

@@ -134,7 +134,36 @@ def msckf_batch():
     np.savez(os.path.join(OUT, "msckf_batch.npz"), z=z, mean=np.array(means), P=np.array(Ps), outliers=np.array(outs))
 
 
+def dead_reckon():
+    """DeadReckon::updatePose delta poses (src/core/DeadReckon.hpp:129-239, :246-286): oracle, cross-checked against the
+    numpy restatement that evaluates the reference's full 4x4 expression; plus two Msckf predicts driven by them."""
+    rng = np.random.default_rng(0x5EED0DE)
+    n = 64
+    u = np.concatenate([rng.uniform(0.005, 0.1, (n, 1)), rng.normal(0, 1.0, (n, 3)), rng.normal(0, 0.5, (n, 3)),
+                        rng.normal(0, 1.0, (n, 3)), rng.normal(0, 0.5, (n, 3))], axis=1)
+    u[0, 1:] = 0.0                      # standing still: identity delta
+    u[1, 4:7] = u[1, 10:13] = 0.0       # no rotation
+    d = o.dead_reckon_delta(u)
+    e = np.array([npc.dead_reckon_delta(r) for r in u])
+    assert np.abs(d - e).max() <= 1e-15, np.abs(d - e).max()
+    assert np.allclose(d[0], [0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0])
+    s = sc.synthetic_msckf(8, 2, m=2, seed=77)
+    means, Ps = [], []
+    for b in range(8):
+        f = o.Msckf(2, s["mean"][b], s["P"][b])
+        g = npc.Msckf(2, s["mean"][b], s["P"][b])
+        for step in range(2):
+            assert f.predict(o.pm_dead_reckon(u[8 * step + b]), s["Q"]) == 0
+            g.predict(lambda x: npc.pm_dead_reckon(x, u[8 * step + b]), s["Q"])
+            check(f.lay, f.mean, f.P, g.mean, g.P, f"dead reckon predict {b} {step}")
+        means.append(f.mean)
+        Ps.append(f.P)
+    # inputs of the predicts: scenarios.synthetic_msckf(8, 2, m=2, seed=77), regenerated by the tests
+    np.savez(os.path.join(OUT, "dead_reckon.npz"), u=u, delta=d, mean=np.array(means), P=np.array(Ps))
+
+
 if __name__ == "__main__":
+    dead_reckon()
     usckf_unit_test()
     usckf_spd()
     msckf_unit_test()

@@ -22,7 +22,8 @@ def res():
     import __graft_entry__ as ge
     ge.build()
     import facade_build
-    return facade_build.run()
+    u = np.load(os.path.join(G, "dead_reckon.npz"))["u"][5]
+    return facade_build.run(u)
 
 
 @pytest.mark.parametrize("k", [0, 4, 8])
@@ -56,3 +57,13 @@ def test_usckf_unit_test_scenario_through_cpp_facade(res):
         assert rel(res[f"usckf_pred{i}_P"], g[f"pred{i}_P"]) <= TOL
         assert np.abs(o.boxminus(lay, res[f"usckf_pred{i}_mean"][:, 0], g[f"pred{i}_mean"])).max() <= TOL
     assert int(res["usckf_literal_update_status"][0, 0]) & 1     # SLK_ST_LLT_FAIL
+
+
+def test_dead_reckon_model_through_cpp_facade(res):
+    # slk::DeadReckonModel (src/core/DeadReckon.hpp:129-239 fused into predict) against the CPU oracle
+    u = np.load(os.path.join(G, "dead_reckon.npz"))["u"][5]
+    lay = o.layout(o.MULTI, 1)
+    f = o.Msckf(1, o.identity_state(lay), 0.025 * np.eye(18))
+    assert f.predict(o.pm_dead_reckon(u), 0.01 * np.eye(12)) == 0
+    assert rel(res["dead_reckon_P"], f.P) <= TOL
+    assert np.abs(o.boxminus(lay, res["dead_reckon_mean"][:, 0], f.mean)).max() <= TOL

@@ -352,3 +352,40 @@ def test_msckf_window_resize_keeps_working(slk):
     for b in range(3):
         assert rel(f.getPk()[b], P[b].reshape(48, 48).T) <= TOL
         assert mean_err(lay, f.muState()[b], mean[b]) <= TOL
+
+
+def test_dead_reckon_delta_and_fused_predict(slk):
+    # DeadReckon::updatePose (src/core/DeadReckon.hpp:129-239): batch op and the fused process model
+    g = np.load(os.path.join(G, "dead_reckon.npz"))
+    u = g["u"]
+    s = sc.synthetic_msckf(8, 2, m=2, seed=77)
+    lay = o.layout(o.MULTI, 2)
+    f = slk.Msckf(s["mean"], s["P"])
+    for blk in range(8):                                   # the op works on the handle's batch of 8
+        d = f.dead_reckon(u[8 * blk:8 * blk + 8])
+        assert np.abs(d - g["delta"][8 * blk:8 * blk + 8]).max() <= 1e-14
+    h = slk.Msckf(s["mean"], s["P"])                       # same predicts through the explicit delta poses
+    for step in range(2):
+        f.predict(slk.PM_DEAD_RECKON, u[8 * step:8 * step + 8], s["Q"])
+        h.predict(slk.PM_DELTA_POSE, g["delta"][8 * step:8 * step + 8], s["Q"])
+    assert (f.status() == 0).all()
+    Pg, Mg, Ph, Mh = f.getPk(), f.muState(), h.getPk(), h.muState()
+    for b in range(8):
+        assert rel(Pg[b], g["P"][b]) <= TOL and mean_err(lay, Mg[b], g["mean"][b]) <= TOL
+        assert rel(Pg[b], Ph[b]) <= 1e-13 and mean_err(lay, Mg[b], Mh[b]) <= 1e-13
+    # device-resident inputs and outputs (SLK_DEVICE) without any other runtime: a second handle's buffers are the
+    # scratch -- its mean buffer [8][27] carries the inputs (row stride 27), its covariance buffer takes the result
+    lib = slk.load_library()
+    scratch = slk.Msckf(s["mean"], s["P"])
+    rows = np.zeros((8, 27))
+    rows[:, :13] = u[:8]
+    import ctypes as C
+    assert lib.slk_set_state(scratch._h, rows.ctypes.data, None, slk.HOST) == 0
+    lib.slk_mean_device_ptr.restype = C.c_void_p
+    lib.slk_cov_device_ptr.restype = C.c_void_p
+    src, dst = lib.slk_mean_device_ptr(scratch._h), lib.slk_cov_device_ptr(scratch._h)
+    assert lib.slk_dead_reckon(f._h, C.c_void_p(src), 27, C.c_void_p(dst), slk.DEVICE) == 0
+    f.sync()                                               # the two handles own different streams
+    out = np.zeros((8, 24 * 24))
+    assert lib.slk_get_state(scratch._h, None, out.ctypes.data, slk.HOST) == 0
+    assert np.abs(out.reshape(-1)[:104].reshape(8, 13) - g["delta"][:8]).max() <= 1e-14

@@ -95,3 +95,28 @@ def test_usckf_spd_golden_and_np_crosscheck():
         assert rel(f.P, g["P"][b]) <= TOL and rel(gnp.P, g["P"][b]) <= TOL
         assert np.abs(o.boxminus(f.lay, f.mean, g["mean"][b])).max() <= TOL
         assert np.abs(o.boxminus(f.lay, gnp.mean, g["mean"][b])).max() <= TOL
+
+
+def test_dead_reckon_golden_and_np_crosscheck():
+    # DeadReckon::updatePose delta pose (src/core/DeadReckon.hpp:129-239, updateAttitude :246-286) and two
+    # Msckf predicts driven by it (SLK_PM_DEAD_RECKON)
+    g = np.load(os.path.join(G, "dead_reckon.npz"))
+    u = g["u"]
+    d = o.dead_reckon_delta(u)
+    assert np.abs(d - g["delta"]).max() <= 1e-15
+    e = np.array([npc.dead_reckon_delta(r) for r in u])        # the reference's full 4x4 expression
+    assert np.abs(e - g["delta"]).max() <= 1e-15
+    assert np.allclose(d[0], [0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0])            # standing still
+    assert np.allclose(d[1, 3:7], [0, 0, 0, 1]) and np.allclose(d[1, 0:3], 0.5 * u[1, 0] * (u[1, 1:4] + u[1, 7:10]))
+    assert np.allclose(np.linalg.norm(d[:, 3:7], axis=1), 1.0, atol=1e-15)
+    # constant angular velocity about one axis: third-order integration vs the exact rotation
+    dt, w = 0.01, np.array([0.0, 0.0, 0.7])
+    q = o.dead_reckon_delta(np.concatenate([[dt], np.zeros(3), w, np.zeros(3), w]))[3:7]
+    assert abs(2.0 * np.arctan2(q[2], q[3]) - dt * 0.7) < 1e-9
+    s = sc.synthetic_msckf(8, 2, m=2, seed=77)
+    for b in range(8):
+        f = o.Msckf(2, s["mean"][b], s["P"][b])
+        for step in range(2):
+            assert f.predict(o.pm_dead_reckon(u[8 * step + b]), s["Q"]) == 0
+        assert float(np.abs(o.boxminus(f.lay, f.mean, g["mean"][b])).max()) <= 1e-13
+        assert rel(f.P, g["P"][b]) <= 1e-13
