@@ -155,6 +155,12 @@ int slk_usckf_cloning(slk_filter *f, int mode);
 int slk_usckf_set_measurement(slk_filter *f, int mode, const double *z, int n, const double *R, int where);
 /* Msckf sliding window: caller-side push/pop on muState().sensorsk + setPk (Msckf.hpp:381-395) */
 int slk_msckf_resize(slk_filter *f, int n_clones);
+/* ... and the same on the device, so that a trajectory never round-trips through the host (the reference has no
+ *     such call: its callers push/pop muState().sensorsk and setPk, Msckf.hpp:381-395, State.hpp:342, :373-396):
+ *     clone_pose appends a SensorState equal to the current pose (pos, orient) whose covariance rows / columns copy
+ *     the pose's (J P J^T, J = [I; E_pose]); drop_clone removes clone `index` (0 = oldest) with its 6 rows / columns. */
+int slk_msckf_clone_pose(slk_filter *f);
+int slk_msckf_drop_clone(slk_filter *f, int index);
 
 /* ---- arithmetic of the covariance rebuild (Msckf.hpp:665 -> :574-589): SLK_PREC_F64 (default, the
  *      parity path), SLK_PREC_F32 (fp32 MFMA) or SLK_PREC_BF16 (bf16 operands, fp32 accumulation).

@@ -338,6 +338,33 @@ static int launch(slk_filter *f, const KArgs &a)
     return f->lay.kind == SLK_MSCKF ? launch_msckf(f, a) : launch_usckf(f, a);
 }
 
+// Sliding window on the device: the reference leaves clone management to the caller
+// (muState().sensorsk push/pop + setPk, Msckf.hpp:381-395; MultiState layout State.hpp:342, :373-396).
+// op 1: append a clone of the current pose; its covariance rows / columns are those of the pose (J P J^T with
+//       J = [I; E_pose], the MSCKF state augmentation for an identity sensor offset).
+// op 2: drop clone `idx`: its 7 stored values and its 6 rows / columns disappear.
+// grid (tiles of the new N x N matrix, B); the mean is moved by the first threads of tile 0.
+__global__ void msckf_window_kernel(const double *mean, const double *P, double *nmean, double *nP, int k_old, int op, int idx)
+{
+    const int b = blockIdx.y;
+    const int N = 12 + 6 * k_old, Nq = 13 + 7 * k_old;
+    const int Nn = op == 1 ? N + 6 : N - 6, Nqn = op == 1 ? Nq + 7 : Nq - 7;
+    const double *m = mean + (size_t)b * Nq, *Pb = P + (size_t)b * N * N;
+    double *mo = nmean + (size_t)b * Nqn, *Po = nP + (size_t)b * Nn * Nn;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    auto tsrc = [&](int t) { return op == 1 ? (t < N ? t : t - N) : (t < 12 + 6 * idx ? t : t + 6); };
+    if (e < Nn * Nn) {
+        const int r = e % Nn, c = e / Nn;
+        Po[e] = Pb[tsrc(r) + (size_t)tsrc(c) * N];
+    }
+    if (e < Nqn) {
+        int ssrc;
+        if (op == 1) ssrc = e < Nq ? e : e - Nq;             // pos[3] quat[4] of the current State sit at 0..6
+        else ssrc = e < 13 + 7 * idx ? e : e + 7;
+        mo[e] = m[ssrc];
+    }
+}
+
 // DeadReckon::updatePose delta poses of a batch (src/core/DeadReckon.hpp:129-239): one thread per filter
 __global__ void dead_reckon_kernel(int B, const double *u, int u_stride, double *delta)
 {
@@ -582,6 +609,34 @@ int slk_usckf_set_measurement(slk_filter *f, int mode, const double *z, int n, c
     f->cfg.n_featuresk = nfk; f->cfg.n_featuresk_l = nfkl;
     return SLK_OK;
 }
+
+static int msckf_window_op(slk_filter *f, int op, int idx)
+{
+    if (!f || f->lay.kind != SLK_MSCKF) return SLK_E_INVALID;
+    const int k_old = f->lay.k, k_new = op == 1 ? k_old + 1 : k_old - 1;
+    if (op == 2 && (idx < 0 || idx >= k_old)) return SLK_E_INVALID;
+    if (12 + 6 * k_new > 208) { g_err = "state dimension above 208 is not supported by this build"; return SLK_E_UNSUPPORTED; }
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    Lay newL = make_lay(SLK_MSCKF, k_new, 0, 0);
+    size_t B = (size_t)f->B;
+    double *nm = nullptr, *nP = nullptr;                      // built out of place, then swapped in
+    HIPCHECK(hipMalloc(&nm, B * newL.Nq * sizeof(double)));
+    HIPCHECK(hipMalloc(&nP, B * (size_t)newL.N * newL.N * sizeof(double)));
+    hipLaunchKernelGGL(msckf_window_kernel, dim3((newL.N * newL.N + 255) / 256, f->B), dim3(256), 0, f->stream,
+                       f->d_mean, f->d_P, nm, nP, k_old, op, idx);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(f->stream));
+    HIPCHECK(hipFree(f->d_mean));
+    HIPCHECK(hipFree(f->d_P));
+    f->d_mean = nm; f->d_P = nP;
+    f->cap_mean = newL.Nq; f->cap_P = (size_t)newL.N * newL.N;
+    f->lay = newL;
+    f->cfg.n_clones = k_new;
+    return SLK_OK;
+}
+
+int slk_msckf_clone_pose(slk_filter *f) { return msckf_window_op(f, 1, 0); }
+int slk_msckf_drop_clone(slk_filter *f, int index) { return msckf_window_op(f, 2, index); }
 
 int slk_msckf_resize(slk_filter *f, int n_clones)
 {

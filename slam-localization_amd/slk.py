@@ -30,7 +30,7 @@ EXPORTS = [
     "slk_step", "slk_predict_sigma_points", "slk_predict_from_sigma", "slk_update_sigma_points",
     "slk_update_from_sigma", "slk_usckf_cloning", "slk_usckf_set_measurement", "slk_msckf_resize",
     "slk_get_outliers", "slk_get_status", "slk_clear_status", "slk_sync", "slk_timer_start", "slk_timer_stop",
-    "slk_selftest_mfma", "slk_set_rebuild_precision", "slk_dead_reckon",
+    "slk_selftest_mfma", "slk_set_rebuild_precision", "slk_dead_reckon", "slk_msckf_clone_pose", "slk_msckf_drop_clone",
 ]
 
 
@@ -79,6 +79,8 @@ def load_library(path=None):
     lib.slk_usckf_cloning.argtypes = [vp, ip]
     lib.slk_usckf_set_measurement.argtypes = [vp, ip, vp, ip, vp, ip]
     lib.slk_msckf_resize.argtypes = [vp, ip]
+    lib.slk_msckf_clone_pose.argtypes = [vp]
+    lib.slk_msckf_drop_clone.argtypes = [vp, ip]
     lib.slk_get_outliers.argtypes = [vp, vp, ip]
     lib.slk_get_status.argtypes = [vp, vp, ip]
     lib.slk_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
@@ -342,6 +344,14 @@ class Msckf(_FilterBatch):
 
     def getPkSingleState(self):                              # Msckf.hpp:368-374
         return self._getP()[:, :12, :12]
+
+    def clone_pose(self):
+        """Device-side muState().sensorsk.push_back(current pose) + setPk(J P J^T) (Msckf.hpp:381-395)."""
+        _check(self._lib.slk_msckf_clone_pose(self._h), "slk_msckf_clone_pose")
+
+    def drop_clone(self, index=0):
+        """Device-side erase of clone `index` (0 = oldest) with its covariance rows / columns."""
+        _check(self._lib.slk_msckf_drop_clone(self._h, int(index)), "slk_msckf_drop_clone")
 
 
 class Usckf(_FilterBatch):

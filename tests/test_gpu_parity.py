@@ -389,3 +389,51 @@ def test_dead_reckon_delta_and_fused_predict(slk):
     out = np.zeros((8, 24 * 24))
     assert lib.slk_get_state(scratch._h, None, out.ctypes.data, slk.HOST) == 0
     assert np.abs(out.reshape(-1)[:104].reshape(8, 13) - g["delta"][:8]).max() <= 1e-14
+
+
+def test_msckf_device_side_window_sliding(slk):
+    # clone push / pop on the device (the reference's callers do muState().sensorsk push/pop + setPk,
+    # Msckf.hpp:381-395); checked against the same index manipulation in numpy and a following step in the oracle
+    B, k, m = 6, 3, 4
+    s = sc.synthetic_msckf(B, k, m=m, seed=4242)
+    f = slk.Msckf(s["mean"], s["P"])
+    N, Nq = s["N"], s["Nq"]
+    mean, P = s["mean"].copy(), s["P"].reshape(B, N, N).copy()
+    # push: the new clone is the current pose, its rows / columns copy the pose's
+    f.clone_pose()
+    src = np.concatenate([np.arange(N), np.arange(6)])
+    P1 = P[:, src][:, :, src]
+    mean1 = np.concatenate([mean, mean[:, 0:7]], axis=1)
+    assert f.N == N + 6 and f.Nq == Nq + 7
+    assert np.array_equal(f.getPk(), P1) and np.array_equal(f.muState(), mean1)
+    # drop the oldest clone
+    f.drop_clone(0)
+    keep_t = np.concatenate([np.arange(12), np.arange(18, N + 6)])
+    keep_s = np.concatenate([np.arange(13), np.arange(20, Nq + 7)])
+    P2, mean2 = P1[:, keep_t][:, :, keep_t], mean1[:, keep_s]
+    assert f.N == N and np.array_equal(f.getPk(), P2) and np.array_equal(f.muState(), mean2)
+    # drop a middle clone, then the window keeps filtering: one step against the oracle
+    f.drop_clone(1)
+    keep_t = np.concatenate([np.arange(18), np.arange(24, N)])
+    keep_s = np.concatenate([np.arange(20), np.arange(27, Nq)])
+    P3, mean3 = P2[:, keep_t][:, :, keep_t], mean2[:, keep_s]
+    assert np.array_equal(f.getPk(), P3) and np.array_equal(f.muState(), mean3)
+    with pytest.raises(slk.SlkError):
+        f.drop_clone(5)
+    # the pushed clone duplicates the pose, so P3 is singular by construction: regularised (as a caller adding the
+    # sensor noise of the new clone would) the window keeps filtering and the step matches the oracle
+    k3 = k - 1
+    N3 = 12 + 6 * k3
+    P3r = P3 + 1e-4 * np.eye(N3)
+    f.setPk(P3r)
+    feat = s["feat"].copy()
+    feat[:, :, 3] = np.minimum(feat[:, :, 3], k3)
+    f.step(slk.PM_DELTA_POSE, s["u"], s["Q"], s["z"], slk.MM_FEATURE_PROJ, feat, s["R"])
+    mo, Po = mean3.copy(), np.ascontiguousarray(P3r).reshape(B, -1)
+    st, out = o.msckf_step_batch(k3, m, 1, mo, Po, s["u"], feat, s["z"], s["Q"], s["R"])
+    assert st == 0
+    np.testing.assert_array_equal(f.outliers(), out)
+    lay = o.layout(o.MULTI, k3)
+    Pg, Mg = f.getPk(), f.muState()
+    for b in range(B):
+        assert rel(Pg[b], Po[b].reshape(N3, N3).T) <= TOL and mean_err(lay, Mg[b], mo[b]) <= TOL
