@@ -437,3 +437,27 @@ def test_msckf_device_side_window_sliding(slk):
     Pg, Mg = f.getPk(), f.muState()
     for b in range(B):
         assert rel(Pg[b], Po[b].reshape(N3, N3).T) <= TOL and mean_err(lay, Mg[b], mo[b]) <= TOL
+
+
+@pytest.mark.parametrize("k,m,B", [(8, 20, 8), (8, 32, 8), (4, 12, 1), (10, 16, 4)])
+def test_msckf_many_measurement_rows_against_oracle(slk, k, m, B):
+    # m > 8 takes the generic row solve, m > 16 the two-tile factorisation of S and the multi-tile S / covXZ path;
+    # m = 32 is the largest block the kernels hold on chip (MAXM); B = 1 is the reference's single filter
+    s = sc.synthetic_msckf(B, k, m=m, seed=900 + m)
+    lay = o.layout(o.MULTI, k)
+    N = s["N"]
+    f = slk.Msckf(s["mean"], s["P"])
+    tot = np.zeros(B, dtype=np.int64)
+    for _ in range(2):
+        f.step(slk.PM_DELTA_POSE, s["u"], s["Q"], s["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+        tot += f.outliers()
+    mean, P = s["mean"].copy(), s["P"].copy()
+    st, out = o.msckf_step_batch(k, m, 2, mean, P, s["u"], s["feat"], s["z"], s["Q"], s["R"])
+    assert st == 0 and (f.status() & ~slk.ST_ALL_REJECTED == 0).all()
+    np.testing.assert_array_equal(tot, out)
+    Pg, Mg = f.getPk(), f.muState()
+    for b in range(B):
+        assert rel(Pg[b], P[b].reshape(N, N).T) <= TOL, b
+        assert mean_err(lay, Mg[b], mean[b]) <= TOL, b
+    with pytest.raises(slk.SlkError):                        # one row more than the kernels hold
+        f.update(np.zeros((B, 34)), slk.MM_FEATURE_PROJ, np.zeros((B, 17, 4)), np.eye(34))
