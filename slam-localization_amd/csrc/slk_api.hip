@@ -188,7 +188,7 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
 {
     KArgs a = a0;
     constexpr bool BIG = NT > 6;
-    Carve cv = carve_step(a.lay, a.m, NT, BIG);
+    Carve cv = carve_step(a.lay, a.m, NT, BIG, a.rebuild_prec);
     if (f->rtab_k != a.lay.k) {                 // layout changed (first launch, slk_msckf_resize): new descriptor table
         std::vector<unsigned long long> tab((size_t)cv.W);
         for (int w = 0; w < cv.W; ++w) tab[w] = rot_item_descriptor(a.lay.N, w);

@@ -18,6 +18,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 
 constexpr int KP = 8;        // sigma points per rebuild panel (2 MFMA k-steps), double-buffered
+#ifndef SLK_WGS
+#define SLK_WGS 4     // workgroups per CU the N <= 64 kernels are built for (register budget 512 / SLK_WGS)
+#endif
 constexpr int MAXM = 32;     // max measurement rows handled on chip
 constexpr int PRED_SCRATCH = 1536;  // doubles of pool used by the 12-DOF predict phase
 
@@ -123,7 +126,7 @@ struct Carve {
 
 // big = large-state variant (NT > 6): the packed factor and the rotation deviations live in a global
 // workspace, LDS keeps the small vectors, the measurement arrays, a Cholesky panel and the MFMA panels
-__host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT, bool big = false)
+__host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT, bool big = false, int prec = 0)
 {
     const int N = L.N, Nq = L.Nq;
     Carve c;
@@ -142,11 +145,14 @@ __host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT, bool bi
     c.small = o;  o += 96;
     c.colbuf = o; o += big ? (4 * 34 + 136) : 4 * ((c.TN > 32 ? c.TN : 32) + 2);   // big: cholm<1..2> buffer + packed 16x16 factor
     c.pool = o;
-    // measurement part: Z[S*m] DZ[N*m] Pxz[N*m] K[N*m] Sm[m*m] G[m*(2m+1)] zbar innov
-    int upd1 = round_up(c.S * m, 2) + 3 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (2 * m + 1), 2)
+    // measurement part: Z[S*m] (the gain K[N*m] reuses its place once the moments are done) DZ[N*m] Pxz[N*m]
+    // Sm[m*m] G[m*(2m+1)] zbar innov
+    int upd1 = round_up(c.S * m, 2) + 2 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (2 * m + 1), 2)
                + 4 * round_up(m, 2);
-    // applyDelta part: rotation deviations (3 per item that differs from X_0) + the double-buffered panels
-    int upd2 = (big ? 0 : round_up(3 * c.W, 2)) + 2 * KP * c.LDD;
+    // applyDelta part: rotation deviations (3 per item that differs from X_0) + the double-buffered panels of the
+    // panel rebuild (N > 64, or the reduced-precision sweep); the K-split rebuild stages nothing
+    const bool panels = big || NT > 4 || prec != 0;
+    int upd2 = (big ? 0 : round_up(3 * c.W, 2)) + (panels ? 2 * KP * c.LDD : 0);
     int pool = PRED_SCRATCH;
     if (upd1 > pool) pool = upd1;
     if (upd2 > pool) pool = upd2;
@@ -498,6 +504,137 @@ __device__ __forceinline__ int cholm_factor(d4 (&acc)[CholM<NT>::NTL], double *L
     wave_sync();
     __builtin_amdgcn_s_setprio(0);
     return fail;
+}
+
+// ------------------------------------------------------------------ the same factorisation over NT waves
+// Wave I owns tile row I (tiles (I, 0..I) in acc[0..I], holding -A like cholm_load): per step every wave of the
+// trailing part publishes its raw panel rows, redoes the 4x4 pivot block, forward-substitutes ONLY its own 16 rows,
+// stores them to the packed factor, and after a second barrier reads the fragments of the tile rows above it for
+// its rank-4 updates.  32 accumulator registers per wave instead of 80 (this is what lets a fourth workgroup
+// share the CU); two workgroup barriers per step; no early exit on a non-positive pivot (the first one is
+// recorded, the NaNs that follow are never used: the caller leaves the filter unchanged).
+template <int NT, class InitFn>
+__device__ __forceinline__ void cholw_load(d4 (&acc)[NT], int n, int lane, int wave, InitFn init)
+{
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int J = 0; J < NT; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = 16 * wave + g + 4 * r, col = 16 * J + c;
+            double v = 0.0;
+            if (J <= wave && wave < NT) {
+                if (row < n && col < n) v = (row >= col) ? init(row, col) : init(col, row);
+                else v = (row == col) ? 1.0 : 0.0;
+            }
+            acc[J][r] = -v;
+        }
+}
+
+template <int NT, class XFn, class YFn>
+__device__ __forceinline__ void cholw_downdate(d4 (&acc)[NT], int n, int kk, int lane, int wave, XFn xel, YFn yel)
+{
+    const int c = lane & 15, g = lane >> 4;
+    if (wave >= NT) return;
+    for (int ks = 0; ks * 4 < kk; ++ks) {
+        const int cc = 4 * ks + g;
+        double bf[NT];
+        const int rw = 16 * wave + c;
+        const bool okw = cc < kk && rw < n;
+        const double af = okw ? xel(rw, cc) : 0.0;           // (-A) += X Y^T
+#pragma unroll
+        for (int J = 0; J < NT; ++J) {
+            int rho = 16 * J + c;
+            bool ok = cc < kk && rho < n && J <= wave;
+            bf[J] = ok ? yel(rho, cc) : 0.0;
+        }
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+            if (J <= wave) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf[J], acc[J], 0, 0, 0);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ int cholw_factor(d4 (&acc)[NT], double *Lp, int n, double *colbuf, int lane, int wave, int *flag)
+{
+    constexpr int LDC = CholM<NT>::LDC;
+    const int c = lane & 15, g = lane >> 4;
+    int fail = -1;
+#pragma unroll
+    for (int JK = 0; JK < NT; ++JK) {
+        const bool part = wave >= JK && wave < NT;
+#pragma unroll
+        for (int c0 = 0; c0 < 16; c0 += 4) {
+            const int k0 = 16 * JK + c0;
+            if (k0 < n) {                                    // uniform over the workgroup
+                // 1. publish the raw panel rows of this wave (four columns)
+                if (part && c >= c0 && c < c0 + 4) {
+                    double *dst = colbuf + (c - c0) * LDC + 16 * wave + g;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[4 * r] = acc[JK][r];
+                }
+                __syncthreads();
+                double frag = 0.0;
+                if (part) {
+                    // 2. pivot block (same in every lane) and this lane's raw panel row; published values are -A
+                    const double *pb = colbuf + k0;
+                    const double p00 = -pb[0], p10 = -pb[1], p20 = -pb[2], p30 = -pb[3];
+                    const double p11 = -pb[LDC + 1], p21 = -pb[LDC + 2], p31 = -pb[LDC + 3];
+                    const double p22 = -pb[2 * LDC + 2], p32 = -pb[2 * LDC + 3], p33 = -pb[3 * LDC + 3];
+                    double v[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) v[b] = -colbuf[b * LDC + 16 * wave + c];
+                    double s0, r0, s1, r1, s2, r2, s3, r3;
+                    if (fail < 0 && !(p00 > 0.0)) fail = k0;
+                    rsqrt_pivot(p00, s0, r0);
+                    const double l10 = p10 * r0, l20 = p20 * r0, l30 = p30 * r0;
+                    const double d1 = fma(-l10, l10, p11);
+                    if (fail < 0 && !(d1 > 0.0)) fail = k0 + 1;
+                    rsqrt_pivot(d1, s1, r1);
+                    const double l21 = fma(-l20, l10, p21) * r1, l31 = fma(-l30, l10, p31) * r1;
+                    const double d2 = fma(-l21, l21, fma(-l20, l20, p22));
+                    if (fail < 0 && !(d2 > 0.0)) fail = k0 + 2;
+                    rsqrt_pivot(d2, s2, r2);
+                    const double l32 = fma(-l31, l21, fma(-l30, l20, p32)) * r2;
+                    const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, p33)));
+                    if (fail < 0 && !(d3 > 0.0)) fail = k0 + 3;
+                    rsqrt_pivot(d3, s3, r3);
+                    // 3. forward substitution of this wave's rows -> fragment = factor entries
+                    const int kap = k0 + g;
+                    const double sg = (g == 0) ? s0 : (g == 1) ? s1 : (g == 2) ? s2 : s3;
+                    const double x0 = v[0] * r0;
+                    const double x1 = fma(-x0, l10, v[1]) * r1;
+                    const double x2 = fma(-x1, l21, fma(-x0, l20, v[2])) * r2;
+                    const double x3 = fma(-x2, l32, fma(-x1, l31, fma(-x0, l30, v[3]))) * r3;
+                    double f = (g == 0) ? x0 : (g == 1) ? x1 : (g == 2) ? x2 : x3;
+                    const int rho = 16 * wave + c;
+                    if (rho == kap) f = sg;
+                    if (rho < kap) f = 0.0;               // strictly upper part of the pivot block
+                    frag = f;
+                    if (rho >= kap && rho < n && kap < n) Lp[pk(n, rho, kap)] = f;
+                }
+                __syncthreads();
+                if (part) {
+                    // 4. rank-4 update of this wave's tiles; fragments of the tile rows above come from the factor
+                    const int kap = k0 + g;
+                    double fj[NT];
+#pragma unroll
+                    for (int J = JK; J < NT; ++J) {
+                        const int rho = 16 * J + c;
+                        const bool in = J < wave && rho >= kap && rho < n && kap < n;
+                        const double lv = Lp[in ? pk(n, rho, kap) : 0];
+                        fj[J] = (J == wave) ? frag : (in ? lv : 0.0);
+                    }
+#pragma unroll
+                    for (int J = JK; J < NT; ++J)
+                        if (J <= wave) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag, fj[J], acc[J], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (wave == NT - 1 && lane == 0) *flag = fail;       // the last tile row takes part in every step
+    __syncthreads();
+    return *flag;
 }
 
 // ------------------------------------------------------------------ blocked Cholesky on a packed factor in memory
@@ -1074,7 +1211,7 @@ struct MfmaTiles32 {
 // ------------------------------------------------------------------ the Msckf step kernel
 // predict (optional) + UKF update with applyDelta (optional), one workgroup per filter.
 template <int NT, int NTHREADS>
-__global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) void msckf_step_kernel(KArgs a)
+__global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? SLK_WGS : (NTHREADS >= 256 && NT <= 6 ? 3 : 1))) void msckf_step_kernel(KArgs a)
 {
     constexpr bool BIG = NT > 6;                           // large state: factor + rotation store in the global workspace
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1086,7 +1223,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
     Lay L = a.lay;
     L.kind = SLK_MSCKF;                                    // this kernel is the Msckf step: fold the layout branches
     const int N = L.N, Nq = L.Nq, m = a.m, nso3 = L.nso3;
-    const Carve cv = carve_step(L, m, NT, BIG);
+    const Carve cv = carve_step(L, m, NT, BIG, a.rebuild_prec);
     const int S = cv.S, LDD = cv.LDD;
     double *Lp = BIG ? a.wsL + (size_t)bidx * pk_size(N) : smem + cv.Lp;
     double *mu = smem + cv.mu, *ref = smem + cv.ref, *pn12 = smem + cv.pn12;
@@ -1146,7 +1283,12 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
     if (a.do_update || a.emit == 2) {
         // ---- sigma points of the full state: Msckf.hpp:228-229 -> :400-431
         int fail;
-        if constexpr (NT <= 4) {
+        constexpr bool WCHOL = NT >= 3 && NT <= 4 && NW >= NT;   // one tile row per wave
+        if constexpr (WCHOL) {
+            d4 acc[NT];
+            cholw_load<NT>(acc, N, lane, wave, Pin);
+            fail = cholw_factor<NT>(acc, Lp, N, colbuf, lane, wave, &ish[45]);
+        } else if constexpr (NT <= 4) {
             if (wave == 0) {
                 d4 acc[CholM<NT>::NTL];
                 cholm_load<NT>(acc, N, lane, Pin);
@@ -1181,14 +1323,14 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
             double *Z = pool;                                   // [S][m]
             double *DZ = Z + round_up(S * m, 2);                // [N][m]: Z_{2j+1} - Z_{2j+2}
             double *Pxz = DZ + round_up(N * m, 2);              // N x m (ld N)
-            double *K = Pxz + round_up(N * m, 2);               // N x m' (ld N)
-            double *Sm = K + round_up(N * m, 2);                // m x m (ld m)
+            double *K = Z;                                      // N x m' (ld N): written after the moments, Z is dead then
+            double *Sm = Pxz + round_up(N * m, 2);              // m x m (ld m)
             double *G = Sm + round_up(m * m, 2);                // packed factor of S / Gauss-Jordan tableau
             double *zbar = G + round_up(m * (2 * m + 1), 2);
             double *innov = zbar + round_up(m, 2);
             int *idx = ish;
             measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lp, Z, DZ, Pxz, Sm, zbar, innov, &ish[42],
-                                           [&](int t) { return Pin(t, t); }, K, N * m);
+                                           [&](int t) { return Pin(t, t); }, colbuf, cv.pool - cv.colbuf);
             SLK_STAMP(6);
             // removeOutliers (:241 -> :723-754) incl. the shifted second erase (:741-744)
             if (tid == 0) {
@@ -1341,7 +1483,13 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
                     SLK_STAMP(10);
                     // ---- Pk -= K S K^T (:262) fused into the load of applyDelta's Cholesky (:263 -> :659-662):
                     // K S = covXZ, so the downdated lower triangle is P(i,j) - sum_c covXZ(i,c) K(j,c).
-                    if constexpr (NT <= 4) {
+                    if constexpr (WCHOL) {
+                        d4 acc[NT];
+                        cholw_load<NT>(acc, N, lane, wave, Pin);
+                        cholw_downdate<NT>(acc, N, mmr, lane, wave, [&](int r, int c) { return Pxz[r + N * idx[c]]; },
+                                           [&](int r, int c) { return K[r + N * c]; });
+                        fail = cholw_factor<NT>(acc, Lp, N, colbuf, lane, wave, &ish[45]);
+                    } else if constexpr (NT <= 4) {
                         if (wave == 0) {
                             d4 acc[CholM<NT>::NTL];
                             cholm_load<NT>(acc, N, lane, Pin);
@@ -1487,9 +1635,15 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
                                 // fragment computed twice -- and the partial tiles are summed through LDS, which
                                 // also lets both triangles go out as contiguous 128-byte rows.
                                 constexpr int NTL = CholM<NT>::NTL;
-                                d4 acc[NTL];
+                                // four waves = 2 halves of the sigma points x 2 halves of the tile list: 5 accumulator
+                                // tiles per wave instead of 10 (registers), two partial sums per tile instead of four
+                                constexpr int TSPLIT = (NW == 4) ? 2 : 1;          // tile groups
+                                constexpr int KSPLIT = NW / TSPLIT;                // sigma-point groups
+                                constexpr int HALF = (NTL + TSPLIT - 1) / TSPLIT;  // tiles per group
+                                const int th = (TSPLIT == 2) ? (wave >> 1) : 0, kh = (TSPLIT == 2) ? (wave & 1) : wave;
+                                d4 acc[HALF];
 #pragma unroll
-                                for (int q = 0; q < NTL; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+                                for (int q = 0; q < HALF; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
                                 const int c16 = lane & 15, g4 = lane >> 4;
                                 // Row t = 16 I + c16 of D, per lane and tile row, in ONE branch-free form
                                 //   D(t, i) = (qm + (qd + f * smem[bas + (c ? y : 0)])) - qr
@@ -1515,7 +1669,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
                                     }
                                 }
                                 const int nks = (S + 3) >> 2;
-                                for (int ks = wave; ks < nks; ks += NW) {
+                                for (int ks = kh; ks < nks; ks += KSPLIT) {
                                     const int i = 4 * ks + g4;
                                     const bool valid = i < S;
                                     const int j = (i > 0) ? ((i - 1) >> 1) : 0;
@@ -1536,22 +1690,24 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
                                     for (int I = 0; I < NT; ++I)
 #pragma unroll
                                         for (int J = 0; J <= I; ++J)
-                                            acc[tile_idx(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[I], frag[J], acc[tile_idx(I, J)], 0, 0, 0);
+                                            if (tile_idx(I, J) / HALF == th)
+                                                acc[tile_idx(I, J) % HALF] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                                                    frag[I], frag[J], acc[tile_idx(I, J) % HALF], 0, 0, 0);
                                 }
                                 __syncthreads();                     // factor, deviations and vectors are dead from here
                                 SLK_STAMP(14);
                                 constexpr int TS = 16 * 17;          // padded 16x16 tile, [col][row]
-                                int TR = cv.total / (NW * TS);
+                                int TR = cv.total / (KSPLIT * TS);
                                 if (TR > NTL) TR = NTL;
                                 double *red = smem;
                                 const int ea = tid & 15, eb = (tid >> 4) & 15;
                                 for (int T0 = 0; T0 < NTL; T0 += TR) {
 #pragma unroll
                                     for (int T = 0; T < NTL; ++T)
-                                        if (T >= T0 && T < T0 + TR) {
-                                            double *dst = red + (wave * TR + (T - T0)) * TS + c16 * 17 + g4;
+                                        if (T / HALF == th && T >= T0 && T < T0 + TR) {
+                                            double *dst = red + (kh * TR + (T - T0)) * TS + c16 * 17 + g4;
 #pragma unroll
-                                            for (int q = 0; q < 4; ++q) dst[4 * q] = acc[T][q];
+                                            for (int q = 0; q < 4; ++q) dst[4 * q] = acc[T % HALF][q];
                                         }
                                     __syncthreads();
                                     const int ntl = (NTL - T0 < TR) ? NTL - T0 : TR;
@@ -1564,14 +1720,14 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT <= 6 ? 3 : 1)) voi
                                             {   // lower triangle: consecutive lanes = consecutive rows of one column
                                                 double sum = 0.0;
 #pragma unroll
-                                                for (int w = 0; w < NW; ++w) sum += src[w * TR * TS + e2 * 17 + ea];
+                                                for (int w = 0; w < KSPLIT; ++w) sum += src[w * TR * TS + e2 * 17 + ea];
                                                 const int row = 16 * I + ea, col = 16 * J + e2;
                                                 if (row < N && col < N) gP[row + (size_t)col * N] = 0.5 * sum;
                                             }
                                             if (I != J) {   // mirrored copy, again contiguous in the fast index
                                                 double sum = 0.0;
 #pragma unroll
-                                                for (int w = 0; w < NW; ++w) sum += src[w * TR * TS + ea * 17 + e2];
+                                                for (int w = 0; w < KSPLIT; ++w) sum += src[w * TR * TS + ea * 17 + e2];
                                                 const int row = 16 * I + e2, col = 16 * J + ea;
                                                 if (row < N && col < N) gP[col + (size_t)row * N] = 0.5 * sum;
                                             }
