@@ -39,6 +39,22 @@ __device__ __forceinline__ void qrot(const Quat &q, double vx, double vy, double
 // For x < 1/4 (rotation below 1 rad, the usual sigma-point spread) the series are summed directly to
 // below 1 ulp (8 terms, Horner) -- no sqrt, no division, no range reduction; MTK itself switches to
 // this series for tiny x (3 terms below eps^(1/4)).  Larger arguments take the libm route.
+// The libm routes are rare (rotations beyond the series' domain) and register-hungry: kept out of line so that
+// their temporaries and polynomial constants do not count against the callers' register budget.
+__device__ __attribute__((noinline)) void cos_sinc_sqrt_libm(double x, double *c, double *s)
+{
+    double sx = sqrt(x), sn, cs;
+    sincos(sx, &sn, &cs);
+    *c = cs;
+    *s = sn / sx;
+}
+__device__ __attribute__((noinline)) double so3_log_scale_libm(double n2, double w)
+{
+    double nv = sqrt(n2);
+    if (nv < 1e-11) nv = 1e-11;
+    return 2.0 / nv * atan(nv / w);
+}
+
 __device__ __forceinline__ void cos_sinc_sqrt(double x, double &c, double &s)
 {
     if (x < 0.25) {
@@ -62,10 +78,7 @@ __device__ __forceinline__ void cos_sinc_sqrt(double x, double &c, double &s)
         c = cc;
         s = ss;
     } else {
-        double sx = sqrt(x), sn, cs;
-        sincos(sx, &sn, &cs);
-        c = cs;
-        s = sn / sx;
+        cos_sinc_sqrt_libm(x, &c, &s);
     }
 }
 
@@ -103,9 +116,7 @@ __device__ __forceinline__ void so3_log(const Quat &q, double &vx, double &vy, d
         f = fma(f, y, 1.0);
         s = 2.0 * f * rw;
     } else {
-        double nv = sqrt(n2);
-        if (nv < 1e-11) nv = 1e-11;
-        s = 2.0 / nv * atan(nv / q.w);
+        s = so3_log_scale_libm(n2, q.w);
     }
     vx = s * q.x; vy = s * q.y; vz = s * q.z;
 }
