@@ -1677,8 +1677,10 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                                     const int jbc = ((j * (2 * N - j + 1)) >> 1) - j + c16;   // pk(N, t, j) = jbc + 16 I
                                     const int i3 = 3 * i;
                                     double frag[NT];
+                                    constexpr int ROWS_A = TileMap<NT>::row(HALF - 1) + 1;   // tile rows the first tile group touches
 #pragma unroll
                                     for (int I = 0; I < NT; ++I) {
+                                        if (TSPLIT == 2 && I >= ROWS_A && th == 0) { frag[I] = 0.0; continue; }
                                         const bool c = (isv[I] ? j : i) < thr[I];
                                         const int y = isv[I] ? jbc + 16 * I : i3;
                                         const double l = smem[bas[I] + (c ? y : 0)];
