@@ -554,12 +554,16 @@ __device__ __forceinline__ void cholw_downdate(d4 (&acc)[NT], int n, int kk, int
     }
 }
 
+// coef: 16 doubles of scratch -- the wave that owns the pivot block does its 4x4 algebra alone (wave-local LDS round
+// trip before the first barrier) and publishes r0..r3, s0..s3, l10 l20 l30 l21 l31 l32; the other waves read them
 template <int NT>
-__device__ __forceinline__ int cholw_factor(d4 (&acc)[NT], double *Lp, int n, double *colbuf, int lane, int wave, int *flag)
+__device__ __forceinline__ int cholw_factor(d4 (&acc)[NT], double *Lp, int n, double *colbuf, double *coef, int lane,
+                                            int wave, int *flag)
 {
     constexpr int LDC = CholM<NT>::LDC;
     const int c = lane & 15, g = lane >> 4;
     int fail = -1;
+    if (wave == 0 && lane == 0) *flag = 0x7fffffff;      // ordered before the atomicMin at the end by the step barriers
 #pragma unroll
     for (int JK = 0; JK < NT; ++JK) {
         const bool part = wave >= JK && wave < NT;
@@ -573,17 +577,13 @@ __device__ __forceinline__ int cholw_factor(d4 (&acc)[NT], double *Lp, int n, do
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dst[4 * r] = acc[JK][r];
                 }
-                __syncthreads();
-                double frag = 0.0;
-                if (part) {
-                    // 2. pivot block (same in every lane) and this lane's raw panel row; published values are -A
+                if (wave == JK) {
+                    // 2a. the owner of the pivot block does the 4x4 algebra for everybody (published values are -A)
+                    wave_sync();
                     const double *pb = colbuf + k0;
                     const double p00 = -pb[0], p10 = -pb[1], p20 = -pb[2], p30 = -pb[3];
                     const double p11 = -pb[LDC + 1], p21 = -pb[LDC + 2], p31 = -pb[LDC + 3];
                     const double p22 = -pb[2 * LDC + 2], p32 = -pb[2 * LDC + 3], p33 = -pb[3 * LDC + 3];
-                    double v[4];
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) v[b] = -colbuf[b * LDC + 16 * wave + c];
                     double s0, r0, s1, r1, s2, r2, s3, r3;
                     if (fail < 0 && !(p00 > 0.0)) fail = k0;
                     rsqrt_pivot(p00, s0, r0);
@@ -599,6 +599,22 @@ __device__ __forceinline__ int cholw_factor(d4 (&acc)[NT], double *Lp, int n, do
                     const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, p33)));
                     if (fail < 0 && !(d3 > 0.0)) fail = k0 + 3;
                     rsqrt_pivot(d3, s3, r3);
+                    if (lane == 0) {
+                        coef[0] = r0; coef[1] = r1; coef[2] = r2; coef[3] = r3;
+                        coef[4] = s0; coef[5] = s1; coef[6] = s2; coef[7] = s3;
+                        coef[8] = l10; coef[9] = l20; coef[10] = l30; coef[11] = l21; coef[12] = l31; coef[13] = l32;
+                    }
+                }
+                __syncthreads();
+                double frag = 0.0;
+                if (part) {
+                    // 2b. the pivot coefficients and this lane's raw panel row
+                    const double r0 = coef[0], r1 = coef[1], r2 = coef[2], r3 = coef[3];
+                    const double s0 = coef[4], s1 = coef[5], s2 = coef[6], s3 = coef[7];
+                    const double l10 = coef[8], l20 = coef[9], l30 = coef[10], l21 = coef[11], l31 = coef[12], l32 = coef[13];
+                    double v[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) v[b] = -colbuf[b * LDC + 16 * wave + c];
                     // 3. forward substitution of this wave's rows -> fragment = factor entries
                     const int kap = k0 + g;
                     const double sg = (g == 0) ? s0 : (g == 1) ? s1 : (g == 2) ? s2 : s3;
@@ -632,9 +648,12 @@ __device__ __forceinline__ int cholw_factor(d4 (&acc)[NT], double *Lp, int n, do
             }
         }
     }
-    if (wave == NT - 1 && lane == 0) *flag = fail;       // the last tile row takes part in every step
+    // every wave owns some pivot blocks: the first failing pivot over all of them (flag preset to -1 by the caller's
+    // barrier-separated write below)
+    if (lane == 0 && fail >= 0) atomicMin(reinterpret_cast<unsigned *>(flag), (unsigned)fail);
     __syncthreads();
-    return *flag;
+    const int f = *flag;
+    return f == 0x7fffffff ? -1 : f;
 }
 
 // ------------------------------------------------------------------ blocked Cholesky on a packed factor in memory
@@ -1287,7 +1306,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
         if constexpr (WCHOL) {
             d4 acc[NT];
             cholw_load<NT>(acc, N, lane, wave, Pin);
-            fail = cholw_factor<NT>(acc, Lp, N, colbuf, lane, wave, &ish[45]);
+            fail = cholw_factor<NT>(acc, Lp, N, colbuf, md, lane, wave, &ish[45]);
         } else if constexpr (NT <= 4) {
             if (wave == 0) {
                 d4 acc[CholM<NT>::NTL];
@@ -1488,7 +1507,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                         cholw_load<NT>(acc, N, lane, wave, Pin);
                         cholw_downdate<NT>(acc, N, mmr, lane, wave, [&](int r, int c) { return Pxz[r + N * idx[c]]; },
                                            [&](int r, int c) { return K[r + N * c]; });
-                        fail = cholw_factor<NT>(acc, Lp, N, colbuf, lane, wave, &ish[45]);
+                        fail = cholw_factor<NT>(acc, Lp, N, colbuf, md, lane, wave, &ish[45]);
                     } else if constexpr (NT <= 4) {
                         if (wave == 0) {
                             d4 acc[CholM<NT>::NTL];
