@@ -1407,8 +1407,9 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 if (sfail < 0 && mmr <= 8) {
                     // row-wise solve held in registers (fully unrolled for m' <= 8)
                     double ginv[8];
+                    const double gd = (lane < mmr) ? 1.0 / G[pk(mmr, lane, lane)] : 0.0;   // one division per lane, then broadcast
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) ginv[c] = (c < mmr) ? 1.0 / G[pk(mmr, c, c)] : 0.0;
+                    for (int c = 0; c < 8; ++c) ginv[c] = __shfl(gd, c, 64);
                     for (int t = tid; t < N; t += NTHREADS) {
                         double x[8];
 #pragma unroll
