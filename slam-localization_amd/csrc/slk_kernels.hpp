@@ -1054,6 +1054,7 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
         cholm_load<1>(acc, 12, tid, pin);
         fail = cholm_factor<1>(acc, Lblk, 12, cb, tid);
     }
+    SLK_STAMP_NR(21);
     if (fail >= 0) return SLK_ST_LLT_FAIL;
     const double *u = a.u ? a.u + (size_t)bidx * a.u_stride : nullptr;
     if (tid < 25) {
@@ -1077,6 +1078,7 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
     wave_sync();
     int it = 0, status = 0;
     double norm;
+    SLK_STAMP_NR(22);
     do {                                            // Msckf.hpp:478-487
         if (tid < 25) state_boxminus(Ys + tid * 13, refs, dbuf + tid * 12);
         wave_sync();
@@ -1096,17 +1098,39 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
         }
         wave_sync();
     } while (norm > 1e-6 && ++it < 10000);
+    SLK_STAMP_NR(23);
+    SLK_NOTE(25, it + 1);
     if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
     // covariance (Msckf.hpp:554-570) + Q (:162)
     if (tid < 25) state_boxminus(Ys + tid * 13, refs, dbuf + tid * 12);
     wave_sync();
     const double *Q = a.Q + (size_t)bidx * a.q_stride;
-    for (int e = tid; e < 144; e += 64) {
+    {   // 1/2 D D^T, D = 12 x 25, on the matrix cores: one 16x16 tile, seven k-steps of four sigma points
+        const int fc = tid & 15, fg = tid >> 4;
+        double fr[7];
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            const int i = 4 * ks + fg;
+            const bool ok = fc < 12 && i < 25;
+            const double v = dbuf[ok ? i * 12 + fc : 0];
+            fr[ks] = ok ? v : 0.0;
+        }
+        d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0;
+#pragma unroll
+        for (int ks = 0; ks < 7; ++ks) {
+            if (ks & 1) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[ks], fr[ks], c1, 0, 0, 0);
+            else c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[ks], fr[ks], c0, 0, 0, 0);
+        }
+        c0 = c0 + c1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = fg + 4 * r;
+            if (row < 12 && fc < 12) Pn[row + 12 * fc] = 0.5 * c0[r] + Q[row + 12 * fc];
+        }
+    }
+    for (int e = tid; WANT_PXY && e < 144; e += 64) {
         int r = e % 12, c = e / 12;
-        double sum = 0.0;
-        for (int i = 0; i < 25; ++i) sum += dbuf[i * 12 + r] * dbuf[i * 12 + c];
-        Pn[e] = 0.5 * sum + Q[e];
-        if (WANT_PXY) {
+        {
             // Pxy = 1/2 sum (XCopy_i [-] mu_old)(X_i [-] mu_new)^T, XCopy_i [-] mu_old = +-L.col(j)
             // (Usckf.hpp:152-153, :691-712)
             double sx = 0.0;

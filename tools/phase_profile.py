@@ -59,6 +59,11 @@ def main():
              "chol2", "mean loop", "final Drot", "MFMA rebuild", "acc->LDS+store"]
     for i, name in enumerate(names):
         print(f"  {name:16s} {np.median(d[:, i]):10.0f}  {100 * np.median(d[:, i]) / np.median(tot):5.1f} %")
+    if (t[ok][:, 21] > 0).all():      # sub-stamps of the predict phase (wave 0)
+        x = t[ok].astype(np.float64)
+        print(f"  predict detail: 12x12 Cholesky {np.median(x[:, 21] - x[:, 1]):.0f}, sigma points + f {np.median(x[:, 22] - x[:, 21]):.0f}, "
+              f"manifold mean {np.median(x[:, 23] - x[:, 22]):.0f} ({np.bincount(t[ok][:, 25].astype(int))} trips), "
+              f"final deviations + covariance + copy {np.median(x[:, 2] - x[:, 23]):.0f}")
     if (t[ok][:, 16] > 0).all():      # sub-stamps of the moments phase (thread 0 = wave 0)
         x = t[ok].astype(np.float64)
         print(f"  moments detail (wave 0): stamp5->Pxz done {np.median(x[:, 16] - x[:, 5]):.0f}, "
