@@ -242,6 +242,49 @@ class Msckf:
         return outliers
 
 
+def msckf_update_ekf(filt, z, zmean, H, R, gate=True):
+    """Msckf EKF update (Msckf.hpp:284-349) with numpy/LAPACK: removeOutliers :756-789 (the information matrix is
+    inverted once and indexed with the running block number), reduceDimension :791-816 through numpy's Householder
+    QR (LAPACK dgeqrf uses the same reflector convention as Eigen's makeHouseholder)."""
+    man, N = filt.man, filt.man.N
+    H = np.array(H, dtype=float)
+    R = np.array(R, dtype=float)
+    innov = np.asarray(z, dtype=float) - np.asarray(zmean, dtype=float)
+    info = np.linalg.inv(H @ filt.P @ H.T + R)
+    idx = list(range(len(innov)))
+    outliers, i = 0, 0
+
+    def erase(lst, pos):
+        if pos < len(lst) - 1:
+            del lst[pos]
+        else:
+            del lst[-1]
+
+    while i < len(idx) // 2:
+        r = innov[[idx[2 * i], idx[2 * i + 1]]]
+        d2 = r @ info[2 * i:2 * i + 2, 2 * i:2 * i + 2] @ r
+        if gate and not d2 < CHI2_95[2]:
+            erase(idx, 2 * i)
+            erase(idx, 2 * i + 1)
+            outliers += 1
+        else:
+            i += 1
+    if idx and len(idx) < N:
+        return outliers, "rows"
+    if idx:
+        Hq, Rq, rq = H[idx], R[np.ix_(idx, idx)], innov[idx]
+        Qf, Rf = np.linalg.qr(Hq, mode="complete")
+        thinQ = Qf[:, :N]
+        Hr = np.triu(Rf)[:N, :N]
+        rn = thinQ.T @ rq
+        Rn = thinQ.T @ Rq @ thinQ
+        S = Hr @ filt.P @ Hr.T + Rn
+        K = filt.P @ Hr.T @ np.linalg.inv(S)
+        filt.P = filt.P - K @ S @ K.T
+        filt.mean = man.plus(filt.mean, K @ rn)
+    return outliers, None
+
+
 class Usckf:
     def __init__(self, nfk, nfkl, mean, P):
         self.nfk, self.nfkl = nfk, nfkl

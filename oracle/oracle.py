@@ -341,6 +341,18 @@ class Msckf:
                                      C.byref(no))
         return st, no.value
 
+    def update_ekf(self, z, zmean, H, R, gate=True):
+        """EKF update (Msckf.hpp:284-349) with zmean = h(mu) and the m x N Jacobian H of the caller's functor."""
+        z, zmean = _arr(z), _arr(zmean)
+        m = z.size
+        no = C.c_uint(0)
+        L = lib()
+        dp = C.POINTER(C.c_double)
+        L.slko_msckf_update_ekf.argtypes = [C.POINTER(_Msckf), dp, dp, dp, C.c_int, dp, C.c_int, C.POINTER(C.c_uint)]
+        Hc = _colmajor(np.asarray(H, dtype=np.float64).reshape(m, -1))
+        st = L.slko_msckf_update_ekf(self._f, _p(z), _p(zmean), _p(Hc), m, _p(_colmajor(R)), int(gate), C.byref(no))
+        return st, no.value
+
     def check_sigma_points(self):
         a, b = C.c_double(0), C.c_double(0)
         st = lib().slko_msckf_check_sigma_points(self._f, C.byref(a), C.byref(b))

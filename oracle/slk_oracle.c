@@ -22,6 +22,7 @@
 #include "slk_oracle.h"
 
 #include <math.h>
+#include <float.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -751,6 +752,155 @@ int slko_msckf_update(slko_msckf *f, const double *z, int m, slko_measure_fn h, 
     }
     if (n_outliers) *n_outliers = outliers;
     free(X); free(Z); free(zbar); free(innov); free(Sm); free(covXZ); free(d); free(idx);
+    return status;
+}
+
+/* Eigen::HouseholderQR (unblocked sweep; the blocked variant Eigen picks for >= 48 columns applies the same
+ * reflectors in compact WY form).  A (rows x cols, column-major, ld rows) is overwritten with R in its upper
+ * triangle and the essential parts of the reflectors below it; tau[min(rows, cols)].
+ * makeHouseholder: beta = -sign(c0) * ||x||, tau = (beta - c0) / beta, v = (1, tail / (c0 - beta)); an exactly
+ * zero tail gives tau = 0, beta = c0. */
+static void householder_qr(int rows, int cols, double *A, double *tau)
+{
+    int p = rows < cols ? rows : cols;
+    for (int k = 0; k < p; ++k) {
+        double c0 = AT(A, rows, k, k), tail = 0.0;
+        for (int i = k + 1; i < rows; ++i) tail += AT(A, rows, i, k) * AT(A, rows, i, k);
+        double beta, t;
+        if (tail <= DBL_MIN) {
+            t = 0.0; beta = c0;
+            for (int i = k + 1; i < rows; ++i) AT(A, rows, i, k) = 0.0;
+        } else {
+            beta = sqrt(c0 * c0 + tail);
+            if (c0 >= 0.0) beta = -beta;
+            for (int i = k + 1; i < rows; ++i) AT(A, rows, i, k) /= (c0 - beta);
+            t = (beta - c0) / beta;
+        }
+        AT(A, rows, k, k) = beta;
+        tau[k] = t;
+        for (int j = k + 1; j < cols; ++j) {            /* A[k:, j] -= tau v (v^T A[k:, j]) */
+            double w = AT(A, rows, k, j);
+            for (int i = k + 1; i < rows; ++i) w += AT(A, rows, i, k) * AT(A, rows, i, j);
+            w *= t;
+            AT(A, rows, k, j) -= w;
+            for (int i = k + 1; i < rows; ++i) AT(A, rows, i, j) -= AT(A, rows, i, k) * w;
+        }
+    }
+}
+
+/* thinQ = householderQ() * Identity(rows, cols): Msckf.hpp:802-803 */
+static void householder_thin_q(int rows, int cols, const double *A, const double *tau, double *Q)
+{
+    int p = rows < cols ? rows : cols;
+    for (int j = 0; j < cols; ++j)
+        for (int i = 0; i < rows; ++i) AT(Q, rows, i, j) = (i == j) ? 1.0 : 0.0;
+    for (int k = p - 1; k >= 0; --k)
+        for (int j = 0; j < cols; ++j) {
+            double w = AT(Q, rows, k, j);
+            for (int i = k + 1; i < rows; ++i) w += AT(A, rows, i, k) * AT(Q, rows, i, j);
+            w *= tau[k];
+            AT(Q, rows, k, j) -= w;
+            for (int i = k + 1; i < rows; ++i) AT(Q, rows, i, j) -= AT(A, rows, i, k) * w;
+        }
+}
+
+/* Msckf EKF update, Msckf.hpp:284-349: z, zmean = h(mu) and the Jacobian H (m x N, column-major) come from the
+ * caller's functor (:310); removeOutliers :756-789 (information matrix inverted ONCE, its 2x2 blocks indexed with the
+ * running i; rows erased with the same shifted second erase as the UKF overload), reduceDimension :791-816
+ * (needs m' >= N rows), gain and covariance :332-337, state correction by boxplus, guaranteeSPD's result is
+ * discarded (:340).  Returns status bits; SLKO_EKF_ROWS when fewer than N rows survive. */
+int slko_msckf_update_ekf(slko_msckf *f, const double *z, const double *zmean, const double *H, int m,
+                          const double *R, int gate, unsigned *n_outliers)
+{
+    const slko_layout *lay = &f->lay;
+    int N = slko_dof(lay), nq = slko_storage(lay);
+    int status = SLKO_OK;
+    unsigned outliers = 0;
+    double *innov = (double *)malloc(sizeof(double) * m);
+    double *PHt = (double *)malloc(sizeof(double) * (size_t)N * m);
+    double *S0 = (double *)malloc(sizeof(double) * (size_t)m * m);
+    double *info = (double *)malloc(sizeof(double) * (size_t)m * m);
+    int *idx = (int *)malloc(sizeof(int) * (m + 2));
+    for (int r = 0; r < m; ++r) innov[r] = z[r] - zmean[r];                       /* :312 */
+    matmul(N, m, N, f->P, N, 0, H, m, 1, PHt, N);                                 /* P H^T */
+    matmul(m, m, N, H, m, 0, PHt, N, 0, S0, m);
+    for (int i = 0; i < m * m; ++i) S0[i] += R[i];
+    if (slko_inverse(m, S0, info)) status |= SLKO_SINGULAR;                       /* :765-766 */
+    int cnt = m;
+    for (int r = 0; r < m; ++r) idx[r] = r;
+    {
+        const int dof = 2;
+        int i = 0;
+        while (i < cnt / dof) {                                                   /* :771-787 */
+            double r0 = innov[idx[dof * i]], r1 = innov[idx[dof * i + 1]];
+            int a = dof * i, b = dof * i + 1;                                     /* block of the UNREDUCED information matrix */
+            double d2 = r0 * (AT(info, m, a, a) * r0 + AT(info, m, a, b) * r1)
+                      + r1 * (AT(info, m, b, a) * r0 + AT(info, m, b, b) * r1);
+            int ok = gate ? slko_accept_mahalanobis(d2, dof) : 1;
+            if (!ok) {
+                idx_remove(idx, &cnt, dof * i);
+                idx_remove(idx, &cnt, dof * i + 1);
+                outliers++;
+            } else {
+                i++;
+            }
+        }
+    }
+    if (cnt > 0 && cnt < N) {
+        status |= SLKO_EKF_ROWS;              /* reduceDimension would read R.block(0,0,N,N) out of range (:806) */
+    } else if (cnt > 0) {                                                         /* :321 */
+        int mm = cnt;
+        double *Hq = (double *)malloc(sizeof(double) * (size_t)mm * N);
+        double *tq = (double *)malloc(sizeof(double) * N);
+        double *Q1 = (double *)malloc(sizeof(double) * (size_t)mm * N);
+        double *Rr = (double *)malloc(sizeof(double) * (size_t)mm * mm);
+        double *T1 = (double *)malloc(sizeof(double) * (size_t)mm * N);
+        double *Hr = (double *)calloc((size_t)N * N, sizeof(double));
+        double *Rn = (double *)malloc(sizeof(double) * (size_t)N * N);
+        double *rn = (double *)malloc(sizeof(double) * N);
+        double *T2 = (double *)malloc(sizeof(double) * (size_t)N * N);
+        double *S = (double *)malloc(sizeof(double) * (size_t)N * N);
+        double *Sinv = (double *)malloc(sizeof(double) * (size_t)N * N);
+        double *K = (double *)malloc(sizeof(double) * (size_t)N * N);
+        double *KS = (double *)malloc(sizeof(double) * (size_t)N * N);
+        double *KSKt = (double *)malloc(sizeof(double) * (size_t)N * N);
+        double *delta = (double *)malloc(sizeof(double) * N);
+        double *mean_new = (double *)malloc(sizeof(double) * nq);
+        for (int j = 0; j < N; ++j)
+            for (int i = 0; i < mm; ++i) AT(Hq, mm, i, j) = AT(H, m, idx[i], j);
+        for (int j = 0; j < mm; ++j)
+            for (int i = 0; i < mm; ++i) AT(Rr, mm, i, j) = AT(R, m, idx[i], idx[j]);
+        householder_qr(mm, N, Hq, tq);                                            /* :797 */
+        householder_thin_q(mm, N, Hq, tq, Q1);                                    /* :802-803 */
+        for (int j = 0; j < N; ++j)
+            for (int i = 0; i <= j; ++i) AT(Hr, N, i, j) = AT(Hq, mm, i, j);      /* :806, upper triangle of R */
+        for (int j = 0; j < N; ++j) {                                             /* :809 */
+            double sacc = 0;
+            for (int i = 0; i < mm; ++i) sacc += AT(Q1, mm, i, j) * innov[idx[i]];
+            rn[j] = sacc;
+        }
+        matmul(mm, N, mm, Rr, mm, 0, Q1, mm, 0, T1, mm);                          /* :812 */
+        matmul(N, N, mm, Q1, mm, 1, T1, mm, 0, Rn, N);
+        matmul(N, N, N, f->P, N, 0, Hr, N, 1, T2, N);                             /* P H^T */
+        matmul(N, N, N, Hr, N, 0, T2, N, 0, S, N);
+        for (int i = 0; i < N * N; ++i) S[i] += Rn[i];                            /* :324 */
+        if (slko_inverse(N, S, Sinv)) status |= SLKO_SINGULAR;
+        matmul(N, N, N, T2, N, 0, Sinv, N, 0, K, N);                              /* :325 */
+        matmul(N, N, N, K, N, 0, S, N, 0, KS, N);
+        matmul(N, N, N, KS, N, 0, K, N, 1, KSKt, N);
+        for (int i = 0; i < N * N; ++i) f->P[i] -= KSKt[i];                       /* :330 */
+        for (int i = 0; i < N; ++i) {
+            double sacc = 0;
+            for (int j = 0; j < N; ++j) sacc += AT(K, N, i, j) * rn[j];
+            delta[i] = sacc;
+        }
+        slko_boxplus(lay, f->mean, delta, mean_new);                              /* :331 */
+        memcpy(f->mean, mean_new, sizeof(double) * nq);
+        free(Hq); free(tq); free(Q1); free(Rr); free(T1); free(Hr); free(Rn); free(rn); free(T2); free(S); free(Sinv);
+        free(K); free(KS); free(KSKt); free(delta); free(mean_new);
+    }
+    if (n_outliers) *n_outliers = outliers;
+    free(innov); free(PHt); free(S0); free(info); free(idx);
     return status;
 }
 

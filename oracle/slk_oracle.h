@@ -46,7 +46,8 @@ enum {
     SLKO_OK = 0,
     SLKO_LLT_FAIL = 1,        /* non-positive pivot in a Cholesky factorisation */
     SLKO_MEAN_NOT_CONVERGED = 2,
-    SLKO_SINGULAR = 4         /* zero pivot in an LU inverse */
+    SLKO_SINGULAR = 4,        /* zero pivot in an LU inverse */
+    SLKO_EKF_ROWS = 16        /* EKF update: fewer measurement rows than state dimensions survive the gate */
 };
 
 typedef struct {
@@ -106,6 +107,10 @@ typedef struct {
 slko_msckf *slko_msckf_new(int k, const double *mean, const double *P);
 void slko_msckf_free(slko_msckf *f);
 int slko_msckf_predict(slko_msckf *f, slko_process_fn fn, void *ctx, const double *Q);
+/* EKF update, Msckf.hpp:284-349 (removeOutliers :756-789, reduceDimension :791-816): zmean = h(mu) and H (m x N,
+ * column-major) are what the reference's functor h(mu_state, H) returns */
+int slko_msckf_update_ekf(slko_msckf *f, const double *z, const double *zmean, const double *H, int m,
+                          const double *R, int gate, unsigned *n_outliers);
 int slko_msckf_update(slko_msckf *f, const double *z, int m, slko_measure_fn h, void *ctx,
                       const double *R, int gate, unsigned *n_outliers);
 /* pieces, exposed for unit tests */

@@ -162,7 +162,30 @@ def dead_reckon():
     np.savez(os.path.join(OUT, "dead_reckon.npz"), u=u, delta=d, mean=np.array(means), P=np.array(Ps))
 
 
+def msckf_ekf():
+    """Msckf EKF update (Msckf.hpp:284-349): oracle vs the numpy/LAPACK restatement, with outliers, rank-deficient
+    Jacobians (zero velocity columns) and a full (non-isotropic) R."""
+    out = {}
+    for (k, m) in ((1, 24), (4, 48), (8, 72), (8, 128)):
+        e = sc.synthetic_ekf(3, k, m, seed=0xEC0F + k + m)
+        means, Ps, outs = [], [], []
+        for b in range(3):
+            f = o.Msckf(k, e["mean"][b], e["P"][b])
+            g = npc.Msckf(k, e["mean"][b], e["P"][b])
+            st, no = f.update_ekf(e["z"][b], e["zmean"][b], e["H"][b], e["R"][b])
+            no2, flag = npc.msckf_update_ekf(g, e["z"][b], e["zmean"][b], e["H"][b], e["R"][b])
+            assert st == 0 and flag is None and no == no2, (k, m, b, st, no, no2, flag)
+            check(f.lay, f.mean, f.P, g.mean, g.P, f"ekf {k} {m} {b}")
+            means.append(f.mean); Ps.append(f.P); outs.append(no)
+        assert sum(outs) > 0
+        out[f"k{k}_m{m}_mean"] = np.array(means)
+        out[f"k{k}_m{m}_P"] = np.array(Ps)
+        out[f"k{k}_m{m}_outliers"] = np.array(outs)
+    np.savez(os.path.join(OUT, "msckf_ekf.npz"), **out)
+
+
 if __name__ == "__main__":
+    msckf_ekf()
     dead_reckon()
     usckf_unit_test()
     usckf_spd()

@@ -154,3 +154,25 @@ def synthetic_usckf(B, nfk=3, nfkl=9, seed=0x5EED1000):
     return dict(B=B, nfk=nfk, nfkl=nfkl, N=N, Nq=Nq, mean=np.ascontiguousarray(mean), P=np.ascontiguousarray(P),
                 u=np.ascontiguousarray(u), z=np.ascontiguousarray(z), Q=0.1 * 0.01 * np.eye(12),
                 R=0.01 * np.eye(nfk))
+
+
+def synthetic_ekf(B, k, m, seed=0xEC0F, outliers=True):
+    """Inputs of the Msckf EKF update (Msckf.hpp:284-349) for B filters with k clones: what the reference's functor
+    h(mu_state, H) hands back (zmean, H [m x N]) plus z and a non-isotropic R.  The Jacobians have exactly zero
+    columns for velocity / angular velocity (as stacked feature residuals do) and are dense elsewhere: the exact
+    zeros are handled identically by every Householder sweep (tau = 0), whereas a numerically dependent column would
+    make thinQ -- and with a non-isotropic R the result -- depend on rounding noise."""
+    s = synthetic_msckf(B, k, m=2, seed=seed)
+    N = s["N"]
+    rng = np.random.default_rng(seed + 1)
+    H = rng.normal(0, 1.0, (B, m, N))
+    H[:, :, 6:12] = 0.0
+    A = rng.normal(0, 0.05, (B, m, m))
+    R = A @ np.transpose(A, (0, 2, 1)) + 0.02 * np.eye(m)
+    zmean = rng.normal(0, 1.0, (B, m))
+    z = zmean + rng.normal(0, 0.15, (B, m))
+    if outliers:
+        for b in range(B):
+            for r in rng.choice(m // 2, size=1 + b % 3, replace=False):
+                z[b, 2 * r] += 25.0
+    return dict(B=B, k=k, m=m, N=N, Nq=s["Nq"], mean=s["mean"], P=s["P"].reshape(B, N, N), H=H, R=R, z=z, zmean=zmean)

@@ -120,3 +120,45 @@ def test_dead_reckon_golden_and_np_crosscheck():
             assert f.predict(o.pm_dead_reckon(u[8 * step + b]), s["Q"]) == 0
         assert float(np.abs(o.boxminus(f.lay, f.mean, g["mean"][b])).max()) <= 1e-13
         assert rel(f.P, g["P"][b]) <= 1e-13
+
+
+@pytest.mark.parametrize("k,m", [(1, 24), (4, 48), (8, 72), (8, 128)])
+def test_msckf_ekf_update_golden_and_np_crosscheck(k, m):
+    # Msckf EKF update (Msckf.hpp:284-349; removeOutliers :756-789, reduceDimension :791-816)
+    g = np.load(os.path.join(G, "msckf_ekf.npz"))
+    e = sc.synthetic_ekf(3, k, m, seed=0xEC0F + k + m)
+    lay = o.layout(o.MULTI, k)
+    for b in range(3):
+        f = o.Msckf(k, e["mean"][b], e["P"][b])
+        st, no = f.update_ekf(e["z"][b], e["zmean"][b], e["H"][b], e["R"][b])
+        assert st == 0 and no == int(g[f"k{k}_m{m}_outliers"][b])
+        assert float(np.abs(o.boxminus(lay, f.mean, g[f"k{k}_m{m}_mean"][b])).max()) <= 1e-12
+        assert rel(f.P, g[f"k{k}_m{m}_P"][b]) <= 1e-12
+        h = npc.Msckf(k, e["mean"][b], e["P"][b])
+        no2, flag = npc.msckf_update_ekf(h, e["z"][b], e["zmean"][b], e["H"][b], e["R"][b])
+        assert flag is None and no2 == no
+        assert float(np.abs(o.boxminus(lay, f.mean, h.mean)).max()) <= 1e-11 and rel(f.P, h.P) <= 1e-11
+
+
+def test_msckf_ekf_update_known_answers():
+    # gate off, H of full column rank and R = s^2 I: the compression is lossless, the result is the textbook EKF update
+    k, m = 2, 60
+    rng = np.random.default_rng(77)
+    e = sc.synthetic_ekf(1, k, m, seed=321, outliers=False)
+    N = e["N"]
+    H = rng.normal(0, 1, (m, N))
+    R = 0.04 * np.eye(m)
+    P, mean = e["P"][0], e["mean"][0]
+    z, zmean = e["z"][0], e["zmean"][0]
+    f = o.Msckf(k, mean, P)
+    st, no = f.update_ekf(z, zmean, H, R, gate=False)
+    assert st == 0 and no == 0
+    S = H @ P @ H.T + R
+    K = P @ H.T @ np.linalg.inv(S)
+    lay = o.layout(o.MULTI, k)
+    assert rel(f.P, P - K @ S @ K.T) <= 1e-10
+    assert float(np.abs(o.boxminus(lay, f.mean, o.boxplus(lay, mean, K @ (z - zmean)))).max()) <= 1e-10
+    # fewer surviving rows than state dimensions: the reference would index R.block(0,0,N,N) out of range (:806)
+    f = o.Msckf(k, mean, P)
+    st, no = f.update_ekf(z[:N - 4], zmean[:N - 4], H[:N - 4], R[:N - 4, :N - 4], gate=False)
+    assert st == 16 and rel(f.P, P) == 0.0
