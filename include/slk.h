@@ -59,7 +59,9 @@ enum {
     SLK_ST_LLT_FAIL = 1,            /* non-positive Cholesky pivot; that call left the filter unchanged */
     SLK_ST_MEAN_NOT_CONVERGED = 2,  /* manifold mean hit max_it = 10000 (Msckf.hpp:475,489-493) */
     SLK_ST_SINGULAR = 4,            /* innovation covariance not invertible */
-    SLK_ST_ALL_REJECTED = 8         /* every measurement block failed the gate: update skipped (Msckf.hpp:250) */
+    SLK_ST_ALL_REJECTED = 8,        /* every measurement block failed the gate: update skipped (Msckf.hpp:250) */
+    SLK_ST_EKF_ROWS = 16            /* EKF update: fewer rows than state dimensions survive the gate; the reference would
+                                       read R.block(0,0,N,N) out of range (Msckf.hpp:806): update skipped */
 };
 
 /* cloning modes of Usckf (Usckf.hpp:37-42) */
@@ -131,6 +133,14 @@ int slk_dead_reckon(slk_filter *f, const double *u, int u_stride, double *delta,
  *            Usckf 0 = accept_any (Usckf.hpp:249), d = chi-square dof of the whole-vector gate. ---- */
 int slk_update(slk_filter *f, int model, const double *params, int p_stride,
                const double *z, int m, const double *R, int r_stride, int gate, int where);
+
+/* ---- EKF update(z, h, H, R[, mt]): Msckf.hpp:284-349 (Msckf only).  The reference's functor h(mu_state, H) is
+ *      evaluated by the caller at the current mean: zmean [B][m] = h(mu), H [B][m*N] = its Jacobian, m x N column-major
+ *      per filter (Eigen default), m >= N rows (reduceDimension, :791-816, compresses to N).  R as in slk_update.
+ *      gate: 0 = accept all 2-row blocks, 1 = accept_mahalanobis_distance (:285-289, :756-789 incl. its indexing of the
+ *      unreduced information matrix and the shifted second erase).  Outliers: slk_get_outliers. ---- */
+int slk_update_ekf(slk_filter *f, const double *z, const double *zmean, const double *H, int m,
+                   const double *R, int r_stride, int gate, int where);
 
 /* ---- fused predict + update, one kernel launch, state stays on chip between the two
  *      (the benchmark's "filter step") ---- */

@@ -13,6 +13,7 @@
 #include "../../include/slk.h"
 #include "slk_kernels.hpp"
 #include "slk_usckf.hpp"
+#include "slk_ekf.hpp"
 
 using namespace slk;
 
@@ -44,6 +45,7 @@ struct slk_filter {
     unsigned *d_outliers;
     Stage st_u, st_Q, st_mp, st_z, st_R, st_X, st_Z, st_tmpP, st_tmpM;
     Stage ws_L, ws_DR;            // large-state workspaces (N > 96), allocated on first use
+    Stage ws_ekf;                 // EKF update workspace, allocated on first use
     unsigned long long *d_rtab = nullptr;   // Msckf rotation-item descriptors of the current layout
     int rtab_k = -1;
     hipEvent_t ev0, ev1;
@@ -137,7 +139,7 @@ void slk_destroy(slk_filter *f)
     (void)hipSetDevice(f->cfg.device);
     (void)hipStreamSynchronize(f->stream);
     Stage *st[] = {&f->st_u, &f->st_Q, &f->st_mp, &f->st_z, &f->st_R, &f->st_X, &f->st_Z, &f->st_tmpP, &f->st_tmpM,
-                   &f->ws_L, &f->ws_DR};
+                   &f->ws_L, &f->ws_DR, &f->ws_ekf};
     for (Stage *s : st) if (s->p) (void)hipFree(s->p);
     if (f->d_rtab) (void)hipFree(f->d_rtab);
     if (f->d_mean) (void)hipFree(f->d_mean);
@@ -420,6 +422,36 @@ int slk_update(slk_filter *f, int model, const double *params, int p_stride, con
     int rc = fill_update(f, a, model, params, p_stride, z, m, R, r_stride, gate, where);
     if (rc) return rc;
     return launch(f, a);
+}
+
+int slk_update_ekf(slk_filter *f, const double *z, const double *zmean, const double *H, int m,
+                   const double *R, int r_stride, int gate, int where)
+{
+    if (!f || f->lay.kind != SLK_MSCKF || !z || !zmean || !H || !R) return SLK_E_INVALID;
+    const int N = f->lay.N;
+    if (m < N || m > 512 || (m & 1)) return SLK_E_INVALID;       // reduceDimension needs m >= N rows; 2-row blocks
+    if (r_stride != 0 && r_stride < m * m) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    EkfArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = f->B; a.N = N; a.Nq = f->lay.Nq; a.k = f->lay.k; a.m = m; a.gate = gate;
+    a.mean = f->d_mean; a.P = f->d_P; a.status = f->d_status; a.outliers = f->d_outliers;
+    a.r_stride = r_stride;
+    size_t B = (size_t)f->B;
+    int rc = stage_in(f, f->st_z, z, B * m, where, &a.z);
+    if (rc) return rc;
+    rc = stage_in(f, f->st_mp, zmean, B * m, where, &a.zmean);
+    if (rc) return rc;
+    rc = stage_in(f, f->st_X, H, B * m * N, where, &a.H);
+    if (rc) return rc;
+    rc = stage_in(f, f->st_R, R, r_stride ? B * r_stride : (size_t)m * m, where, &a.R);
+    if (rc) return rc;
+    rc = stage_reserve(f, f->ws_ekf, B * ekf_ws_doubles(N, m));
+    if (rc) return rc;
+    a.ws = f->ws_ekf.p;
+    hipLaunchKernelGGL(msckf_ekf_kernel<256>, dim3(f->B), dim3(256), 0, f->stream, a);
+    HIPCHECK(hipGetLastError());
+    return SLK_OK;
 }
 
 int slk_step(slk_filter *f, int pmodel, const double *u, int u_stride, const double *Q, int q_stride,

@@ -20,7 +20,7 @@ HOST, DEVICE = 0, 1
 STATEK, STATEK_L, STATEK_I = 1, 2, 3
 MODEL_EXTERNAL, PM_CONST_VELOCITY, PM_DELTA_POSE, PM_DEAD_RECKON = 0, 1, 2, 3
 MM_VO_RELATIVE, MM_FEATURE_PROJ, MM_POSE_POSITION = 1, 2, 3
-ST_LLT_FAIL, ST_MEAN_NOT_CONVERGED, ST_SINGULAR, ST_ALL_REJECTED = 1, 2, 4, 8
+ST_LLT_FAIL, ST_MEAN_NOT_CONVERGED, ST_SINGULAR, ST_ALL_REJECTED, ST_EKF_ROWS = 1, 2, 4, 8, 16
 E_INVALID, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = -1, -2, -3, -4, -5
 
 # every symbol include/slk.h declares (checked by the CPU test-suite against the built library)
@@ -30,7 +30,7 @@ EXPORTS = [
     "slk_step", "slk_predict_sigma_points", "slk_predict_from_sigma", "slk_update_sigma_points",
     "slk_update_from_sigma", "slk_usckf_cloning", "slk_usckf_set_measurement", "slk_msckf_resize",
     "slk_get_outliers", "slk_get_status", "slk_clear_status", "slk_sync", "slk_timer_start", "slk_timer_stop",
-    "slk_selftest_mfma", "slk_set_rebuild_precision", "slk_dead_reckon", "slk_msckf_clone_pose", "slk_msckf_drop_clone",
+    "slk_selftest_mfma", "slk_set_rebuild_precision", "slk_dead_reckon", "slk_msckf_clone_pose", "slk_msckf_drop_clone", "slk_update_ekf",
 ]
 
 
@@ -70,6 +70,7 @@ def load_library(path=None):
     lib.slk_cov_device_ptr.restype = vp
     lib.slk_predict.argtypes = [vp, ip, vp, ip, vp, ip, ip]
     lib.slk_dead_reckon.argtypes = [vp, vp, ip, vp, ip]
+    lib.slk_update_ekf.argtypes = [vp, vp, vp, vp, ip, vp, ip, ip, ip]
     lib.slk_update.argtypes = [vp, ip, vp, ip, vp, ip, vp, ip, ip, ip]
     lib.slk_step.argtypes = [vp, ip, vp, ip, vp, ip, ip, vp, ip, vp, ip, vp, ip, ip, ip]
     lib.slk_predict_sigma_points.argtypes = [vp, vp, ip]
@@ -344,6 +345,17 @@ class Msckf(_FilterBatch):
 
     def getPkSingleState(self):                              # Msckf.hpp:368-374
         return self._getP()[:, :12, :12]
+
+    def update_ekf(self, z, zmean, H, R, gate=True):
+        """EKF update(z, h, H, R) (Msckf.hpp:284-349): zmean [B, m] = h(mu), H [B, m, N] = its Jacobian (numpy, row/col
+        indexable), evaluated by the caller at the current mean like the reference's functor h(mu_state, H)."""
+        z = np.ascontiguousarray(np.atleast_2d(np.asarray(z, dtype=np.float64)))
+        zm = np.ascontiguousarray(np.atleast_2d(np.asarray(zmean, dtype=np.float64)))
+        m = z.shape[-1]
+        Hc = np.ascontiguousarray(np.transpose(np.asarray(H, dtype=np.float64).reshape(self.B, m, self.N), (0, 2, 1)))
+        ra = _mat(np.asarray(R), self.B, m)
+        _check(self._lib.slk_update_ekf(self._h, z.ctypes.data, zm.ctypes.data, Hc.ctypes.data, m, ra.ptr, ra.stride,
+                                        int(bool(gate)), HOST), "slk_update_ekf")
 
     def clone_pose(self):
         """Device-side muState().sensorsk.push_back(current pose) + setPk(J P J^T) (Msckf.hpp:381-395)."""

@@ -461,3 +461,53 @@ def test_msckf_many_measurement_rows_against_oracle(slk, k, m, B):
         assert mean_err(lay, Mg[b], mean[b]) <= TOL, b
     with pytest.raises(slk.SlkError):                        # one row more than the kernels hold
         f.update(np.zeros((B, 34)), slk.MM_FEATURE_PROJ, np.zeros((B, 17, 4)), np.eye(34))
+
+
+@pytest.mark.parametrize("k,m", [(1, 24), (4, 48), (8, 72), (8, 128)])
+def test_msckf_ekf_update_against_golden_and_oracle(slk, k, m):
+    # Msckf EKF update (Msckf.hpp:284-349): gate on the unreduced information matrix with the shifted
+    # second erase, Householder compression to N rows, gain, covariance, boxplus -- batch of 3 + 5 more filters
+    g = np.load(os.path.join(G, "msckf_ekf.npz"))
+    e = sc.synthetic_ekf(3, k, m, seed=0xEC0F + k + m)
+    lay = o.layout(o.MULTI, k)
+    f = slk.Msckf(e["mean"], e["P"])
+    f.update_ekf(e["z"], e["zmean"], e["H"], e["R"])
+    assert (f.status() == 0).all()
+    np.testing.assert_array_equal(f.outliers(), g[f"k{k}_m{m}_outliers"])
+    Pg, Mg = f.getPk(), f.muState()
+    for b in range(3):
+        assert rel(Pg[b], g[f"k{k}_m{m}_P"][b]) <= TOL, b
+        assert mean_err(lay, Mg[b], g[f"k{k}_m{m}_mean"][b]) <= TOL, b
+    # a second, ungated batch straight against the oracle
+    e = sc.synthetic_ekf(5, k, m, seed=4000 + k + m)
+    f = slk.Msckf(e["mean"], e["P"])
+    f.update_ekf(e["z"], e["zmean"], e["H"], e["R"], gate=False)
+    assert (f.status() == 0).all() and (f.outliers() == 0).all()
+    Pg, Mg = f.getPk(), f.muState()
+    for b in range(5):
+        r = o.Msckf(k, e["mean"][b], e["P"][b])
+        st, no = r.update_ekf(e["z"][b], e["zmean"][b], e["H"][b], e["R"][b], gate=False)
+        assert st == 0 and no == 0
+        assert rel(Pg[b], r.P) <= TOL and mean_err(lay, Mg[b], r.mean) <= TOL
+
+
+def test_msckf_ekf_update_edge_cases(slk):
+    k, m = 2, 40
+    e = sc.synthetic_ekf(4, k, m, seed=515, outliers=False)
+    N = e["N"]
+    f = slk.Msckf(e["mean"], e["P"])
+    with pytest.raises(slk.SlkError):                        # fewer rows than state dimensions (reduceDimension, :806)
+        f.update_ekf(e["z"][:, :N - 2], e["zmean"][:, :N - 2], e["H"][:, :N - 2], e["R"][:, :N - 2, :N - 2])
+    # most blocks are outliers: fewer than N rows survive -> status bit, filter untouched (the oracle agrees)
+    z = e["z"].copy()
+    z[:, 0:m - 8] += 60.0
+    f.update_ekf(z, e["zmean"], e["H"], e["R"])
+    for b in range(4):
+        r = o.Msckf(k, e["mean"][b], e["P"][b])
+        st, no = r.update_ekf(z[b], e["zmean"][b], e["H"][b], e["R"][b])
+        assert st == 16 and no == f.outliers()[b] and f.status()[b] == slk.ST_EKF_ROWS
+    assert np.array_equal(f.getPk(), e["P"]) and np.array_equal(f.muState(), e["mean"])
+    # an indefinite R makes H P H^T + R non-SPD: reported, filter untouched
+    f.clear_status()
+    f.update_ekf(e["z"], e["zmean"], e["H"], -np.eye(m))
+    assert (f.status() & slk.ST_SINGULAR).all() and np.array_equal(f.getPk(), e["P"])
