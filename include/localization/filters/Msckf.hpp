@@ -148,6 +148,20 @@ namespace localization
             return finish_update();
         }
 
+        /**@brief EKF update (Msckf.hpp:284-349): h(mu_state, H) returns the expected measurement and fills the
+         * Jacobian H (m x N) at the current mean, exactly like the reference's functor (:310); the gate, the Householder
+         * compression (reduceDimension) and the gain run on the GPU.  Returns the outlier count (:348). */
+        template <typename _Measurement, typename _MeasurementModel, class Jac, class Cov>
+        unsigned int update(const _Measurement &z, _MeasurementModel hfun, Jac &H, const Cov &R, bool gate = true)
+        {
+            pull_mean();
+            const _Measurement mean_z = hfun(mu_state, H);
+            const int m = (int)z.size();
+            slk::check(slk_update_ekf(h.get(), z.data(), mean_z.data(), H.data(), m, R.data(), 0, gate ? 1 : 0, SLK_HOST),
+                       "slk_update_ekf");
+            return finish_update();
+        }
+
         void muSingleState(const _SingleState &state)            // Msckf.hpp:351-354
         {
             pull_mean(); pull_cov();

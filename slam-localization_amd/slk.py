@@ -348,7 +348,15 @@ class Msckf(_FilterBatch):
 
     def update_ekf(self, z, zmean, H, R, gate=True):
         """EKF update(z, h, H, R) (Msckf.hpp:284-349): zmean [B, m] = h(mu), H [B, m, N] = its Jacobian (numpy, row/col
-        indexable), evaluated by the caller at the current mean like the reference's functor h(mu_state, H)."""
+        indexable), evaluated by the caller at the current mean like the reference's functor h(mu_state, H).
+        Device tensors are taken as they are: z, zmean [B, m], H [B, N, m] (= m x N column-major per filter), R column-major."""
+        if _is_dev(H):
+            m = int(z.shape[-1])
+            ra = _mat(R, self.B, m)
+            assert z.is_contiguous() and zmean.is_contiguous() and H.is_contiguous()
+            _check(self._lib.slk_update_ekf(self._h, z.data_ptr(), zmean.data_ptr(), H.data_ptr(), m, ra.ptr, ra.stride,
+                                            int(bool(gate)), DEVICE), "slk_update_ekf")
+            return
         z = np.ascontiguousarray(np.atleast_2d(np.asarray(z, dtype=np.float64)))
         zm = np.ascontiguousarray(np.atleast_2d(np.asarray(zmean, dtype=np.float64)))
         m = z.shape[-1]

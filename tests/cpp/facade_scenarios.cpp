@@ -152,6 +152,40 @@ static void dead_reckon_scenario(const double *u)
     dump("dead_reckon_P", filter.getPk());
 }
 
+// EKF update through the facade (Msckf.hpp:284-349): the functor has the reference's h(mu_state, H) form; the
+// Jacobian and the expected measurement are closed-form patterns the Python test rebuilds
+struct PatternEkfModel
+{
+    int m, N;
+    slk::Vector operator()(const WMultiState &, slk::Matrix &H) const
+    {
+        slk::Vector zm(m);
+        for (int i = 0; i < m; ++i) {
+            zm[i] = std::cos(0.3 * i);
+            for (int j = 0; j < N; ++j) H(i, j) = (j >= 6 && j < 12) ? 0.0 : std::sin(0.37 * i + 1.3 * j) + ((i % N) == j ? 2.0 : 0.0);
+        }
+        return zm;
+    }
+};
+
+static void ekf_scenario()
+{
+    const int k = 1, N = 18, m = 24;
+    WMultiState statek_0;
+    statek_0.sensorsk.resize(k);
+    slk::Matrix Pk_0 = 0.025 * slk::Matrix::Identity(N, N);
+    MultiStateFilter filter(statek_0, Pk_0);
+    slk::Matrix H(m, N), R = 0.04 * slk::Matrix::Identity(m, m);
+    slk::Vector z(m);
+    for (int i = 0; i < m; ++i) z[i] = std::cos(0.3 * i) + 0.1 * std::sin(1.0 * i);
+    z[6] += 30.0;                                              // one outlier block
+    PatternEkfModel hm; hm.m = m; hm.N = N;
+    unsigned outliers = filter.update(z, hm, H, R);
+    dump_mean("ekf_mean", filter.muState(), 20);
+    dump("ekf_P", filter.getPk());
+    std::printf("ekf_outliers 1 1 %u\n", outliers);
+}
+
 int main(int argc, char **argv)
 {
     int st = 0;
@@ -163,6 +197,7 @@ int main(int argc, char **argv)
     for (int k : {0, 4, 8}) st |= msckf_scenario(k, false);
     st |= msckf_scenario(4, true);
     usckf_scenario();
+    ekf_scenario();
     std::printf("msckf_status 1 1 %d\n", st);
     return 0;
 }

@@ -67,3 +67,21 @@ def test_dead_reckon_model_through_cpp_facade(res):
     assert f.predict(o.pm_dead_reckon(u), 0.01 * np.eye(12)) == 0
     assert rel(res["dead_reckon_P"], f.P) <= TOL
     assert np.abs(o.boxminus(lay, res["dead_reckon_mean"][:, 0], f.mean)).max() <= TOL
+
+
+def test_ekf_update_through_cpp_facade(res):
+    # Msckf::update(z, h, H, R) EKF overload (Msckf.hpp:284-349) with a functor of the reference's h(mu_state, H) form
+    k, N, m = 1, 18, 24
+    i = np.arange(m)[:, None]
+    j = np.arange(N)[None, :]
+    H = np.sin(0.37 * i + 1.3 * j) + np.where((i % N) == j, 2.0, 0.0)
+    H[:, 6:12] = 0.0
+    zmean = np.cos(0.3 * np.arange(m))
+    z = zmean + 0.1 * np.sin(1.0 * np.arange(m))
+    z[6] += 30.0
+    lay = o.layout(o.MULTI, k)
+    f = o.Msckf(k, o.identity_state(lay), 0.025 * np.eye(N))
+    st, no = f.update_ekf(z, zmean, H, 0.04 * np.eye(m))
+    assert st == 0 and no == int(res["ekf_outliers"][0, 0]) and no >= 1
+    assert rel(res["ekf_P"], f.P) <= TOL
+    assert np.abs(o.boxminus(lay, res["ekf_mean"][:, 0], f.mean)).max() <= TOL
