@@ -449,7 +449,18 @@ int slk_update_ekf(slk_filter *f, const double *z, const double *zmean, const do
     rc = stage_reserve(f, f->ws_ekf, B * ekf_ws_doubles(N, m));
     if (rc) return rc;
     a.ws = f->ws_ekf.p;
-    hipLaunchKernelGGL(msckf_ekf_kernel<256>, dim3(f->B), dim3(256), 0, f->stream, a);
+    const size_t lds = ekf_lds_doubles(N, m) * sizeof(double);
+    if (m <= 128 && N <= 64 && lds <= 140 * 1024) {               // factorisations, QR and thinQ resident in LDS
+        auto kern = msckf_ekf_lds_kernel<1024>;
+        static size_t configured = 0;
+        if (lds > configured) {
+            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured = lds;
+        }
+        hipLaunchKernelGGL(kern, dim3(f->B), dim3(1024), lds, f->stream, a);
+    } else {
+        hipLaunchKernelGGL(msckf_ekf_kernel<256>, dim3(f->B), dim3(256), 0, f->stream, a);
+    }
     HIPCHECK(hipGetLastError());
     return SLK_OK;
 }

@@ -283,4 +283,282 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_kernel(EkfArgs a)
     if (tid == 0 && status) atomicOr(a.status + b, status);
 }
 
+// ------------------------------------------------------------------ LDS-resident variant (m <= 128, N <= 64)
+// Same steps; the two factorisations, the inverse factor, the QR sweep and thinQ live in LDS (132 KB: one workgroup
+// per CU), dots over a column are split over four threads.  Everything GEMM-shaped still reads the global workspace.
+template <int NTHREADS>
+__device__ void ekf_cholesky_packed_lds(double *A /* packed lower, column-major */, int n, int tid, int *flag)
+{
+    for (int j = 0; j < n; ++j) {
+        const double d = A[pk(n, j, j)];
+        if (!(d > 0.0)) { if (tid == 0 && *flag < 0) *flag = j; }
+        __syncthreads();
+        const double rs = 1.0 / sqrt(d);
+        const int base = pk(n, j, j) - j;                       // A(i, j) = A[base + i]
+        for (int i = j + 1 + tid; i < n; i += NTHREADS) A[base + i] *= rs;
+        if (tid == 0) A[base + j] = sqrt(d);
+        __syncthreads();
+        // trailing lower triangle in 16 x 16 thread tiles
+        constexpr int TJ = NTHREADS / 16;                       // thread tile: 16 rows x TJ columns
+        const int ti = tid & 15, tj = tid >> 4, rem = n - j - 1, nbr = (rem + 15) >> 4, nbc = (rem + TJ - 1) / TJ;
+        for (int bc = 0; bc < nbc; ++bc)
+            for (int br = (TJ * bc) >> 4; br < nbr; ++br) {
+                const int c = j + 1 + TJ * bc + tj, i = j + 1 + 16 * br + ti;
+                if (i < n && c < n && i >= c) A[pk(n, i, c)] -= A[base + i] * A[base + c];
+            }
+        __syncthreads();
+    }
+}
+
+template <int NTHREADS>
+__global__ __launch_bounds__(NTHREADS) void msckf_ekf_lds_kernel(EkfArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ int idx[136];
+    __shared__ int sh[8];
+    __shared__ double hh[4];
+    __shared__ double infob[3 * 64];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int N = a.N, Nq = a.Nq, m = a.m;
+    double *mean = a.mean + (size_t)b * Nq, *P = a.P + (size_t)b * N * N;
+    const double *z = a.z + (size_t)b * m, *zm = a.zmean + (size_t)b * m, *H = a.H + (size_t)b * m * N;
+    const double *R = a.R + (size_t)b * a.r_stride;
+    double *w = a.ws + (size_t)b * ekf_ws_doubles(N, m);
+    double *PHt = w;                w += (size_t)N * m;
+    w += 2 * (size_t)m * m;                                   // (S0, Li of the global variant: unused here)
+    double *Rr = w;                 w += (size_t)m * m;
+    w += 2 * (size_t)m * N;                                   // (Hq, Q1 of the global variant)
+    double *T1 = w;                 w += (size_t)m * N;
+    double *HrG = w;                w += (size_t)N * N;
+    double *Rn = w;                 w += (size_t)N * N;
+    w += 3 * (size_t)N * N;
+    double *Pn = w;                 w += (size_t)N * N;
+    double *innov = w;              w += m;
+    double *rq = w;                 w += m;
+    double *tau = w;                w += 2 * m;
+    double *rn = w;                 w += N;
+    double *delta = w;              w += 3 * N;
+    const int np = pk_size(m);
+    double *L0 = lds, *Li = lds + np;                          // gate phase: packed factor and its inverse
+    if (tid == 0) { sh[0] = m; sh[1] = 0; sh[2] = -1; sh[3] = -1; a.outliers[b] = 0u; }
+    for (int r = tid; r < m; r += NTHREADS) { innov[r] = z[r] - zm[r]; idx[r] = r; }
+    for (int e = tid; e < N * m; e += NTHREADS) {
+        const int i = e % N, j = e / N;
+        double s = 0.0;
+        for (int p = 0; p < N; ++p) s += EKF_AT(P, N, i, p) * EKF_AT(H, m, j, p);
+        EKF_AT(PHt, N, i, j) = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < m * m; e += NTHREADS) {              // lower triangle of S0 = H P H^T + R
+        const int i = e % m, j = e / m;
+        if (i < j) continue;
+        double s = 0.0;
+        for (int p = 0; p < N; ++p) s += EKF_AT(H, m, i, p) * EKF_AT(PHt, N, p, j);
+        L0[pk(m, i, j)] = s + EKF_AT(R, m, i, j);
+    }
+    __syncthreads();
+    ekf_cholesky_packed_lds<NTHREADS>(L0, m, tid, &sh[2]);
+    int status = 0;
+    if (sh[2] >= 0) {
+        status |= SLK_ST_SINGULAR;
+    } else {
+        for (int c = tid; c < m; c += NTHREADS) {              // Li = L0^-1, one column per thread
+            const int cb = pk(m, c, c) - c;                    // Li(i, c) = Li[cb + i]
+            for (int i = c; i < m; ++i) {
+                double s = (i == c) ? 1.0 : 0.0;
+                for (int p = c; p < i; ++p) s -= L0[pk(m, i, p)] * Li[cb + p];
+                Li[cb + i] = s / L0[pk(m, i, i)];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < 3 * (m / 2); e += NTHREADS) {    // the 2x2 diagonal blocks of the information matrix
+            const int blk = e / 3, q = e % 3, r = 2 * blk + (q == 2), c = 2 * blk + (q >= 1);
+            double s = 0.0;
+            for (int p = (r > c ? r : c); p < m; ++p) s += Li[pk(m, p, r)] * Li[pk(m, p, c)];
+            infob[e] = s;                                      // q = 0: (0,0), 1: (0,1), 2: (1,1)
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cnt = m;
+            unsigned nout = 0;
+            int i = 0;
+            while (i < cnt / 2) {
+                const double r0 = innov[idx[2 * i]], r1 = innov[idx[2 * i + 1]];
+                const double i00 = infob[3 * i], i01 = infob[3 * i + 1], i11 = infob[3 * i + 2];
+                const double d2 = r0 * (i00 * r0 + i01 * r1) + r1 * (i01 * r0 + i11 * r1);
+                const bool ok = a.gate ? (d2 < 5.99) : true;
+                if (!ok) {
+                    for (int rep = 0; rep < 2; ++rep) {
+                        int pos = 2 * i + rep, numRows = cnt - 1;
+                        if (pos < numRows) for (int q = pos; q < numRows; ++q) idx[q] = idx[q + 1];
+                        cnt = numRows;
+                    }
+                    nout++;
+                } else {
+                    i++;
+                }
+            }
+            sh[0] = cnt;
+            a.outliers[b] = nout;
+        }
+        __syncthreads();
+        const int mm = sh[0];
+        if (mm > 0 && mm < N) {
+            status |= SLK_ST_EKF_ROWS;
+        } else if (mm > 0) {
+            double *Hq = lds, *Q1 = lds + (size_t)mm * N;      // QR phase: both mm x N, column-major
+            for (int e = tid; e < mm * N; e += NTHREADS) { const int i = e % mm, j = e / mm; EKF_AT(Hq, mm, i, j) = EKF_AT(H, m, idx[i], j); }
+            for (int e = tid; e < mm * mm; e += NTHREADS) { const int i = e % mm, j = e / mm; EKF_AT(Rr, mm, i, j) = EKF_AT(R, m, idx[i], idx[j]); }
+            for (int i = tid; i < mm; i += NTHREADS) rq[i] = innov[idx[i]];
+            __syncthreads();
+            const int col4 = tid >> 2, part = tid & 3;         // four threads per column
+            for (int kk = 0; kk < N; ++kk) {
+                if (tid < 64) {                                // tail norm of column kk by one wave
+                    double part2 = 0.0;
+                    for (int i = kk + 1 + tid; i < mm; i += 64) { const double v = EKF_AT(Hq, mm, i, kk); part2 += v * v; }
+                    for (int o = 32; o >= 1; o >>= 1) part2 += __shfl_xor(part2, o, 64);
+                    if (tid == 0) {
+                        const double c0 = EKF_AT(Hq, mm, kk, kk);
+                        double beta, tk, den;
+                        if (part2 <= 2.2250738585072014e-308) { tk = 0.0; beta = c0; den = 0.0; }
+                        else {
+                            beta = sqrt(c0 * c0 + part2);
+                            if (c0 >= 0.0) beta = -beta;
+                            den = c0 - beta;
+                            tk = (beta - c0) / beta;
+                        }
+                        hh[0] = beta; hh[1] = tk; hh[2] = den;
+                        tau[kk] = tk;
+                    }
+                }
+                __syncthreads();
+                const double tk = hh[1], den = hh[2];
+                for (int i = kk + 1 + tid; i < mm; i += NTHREADS) EKF_AT(Hq, mm, i, kk) = (den != 0.0) ? EKF_AT(Hq, mm, i, kk) / den : 0.0;
+                if (tid == 0) EKF_AT(Hq, mm, kk, kk) = hh[0];
+                __syncthreads();
+                for (int j0 = kk + 1; j0 < N; j0 += NTHREADS / 4) {
+                    const int j = j0 + col4;
+                    double wv = 0.0;
+                    if (j < N) {
+                        if (part == 0) wv = EKF_AT(Hq, mm, kk, j);
+                        for (int i = kk + 1 + part; i < mm; i += 4) wv += EKF_AT(Hq, mm, i, kk) * EKF_AT(Hq, mm, i, j);
+                    }
+                    wv += __shfl_xor(wv, 1, 64);
+                    wv += __shfl_xor(wv, 2, 64);
+                    wv *= tk;
+                    if (j < N) {
+                        if (part == 0) EKF_AT(Hq, mm, kk, j) -= wv;
+                        for (int i = kk + 1 + part; i < mm; i += 4) EKF_AT(Hq, mm, i, j) -= EKF_AT(Hq, mm, i, kk) * wv;
+                    }
+                }
+                __syncthreads();
+            }
+            // thinQ: four threads per column, reflectors in reverse; a column is private to its four threads
+            for (int j0 = 0; j0 < N; j0 += NTHREADS / 4) {
+                const int j = j0 + col4;
+                if (j < N) for (int i = part; i < mm; i += 4) EKF_AT(Q1, mm, i, j) = (i == j) ? 1.0 : 0.0;
+                for (int kk = N - 1; kk >= 0; --kk) {
+                    double wv = 0.0;
+                    if (j < N) {
+                        if (part == 0) wv = EKF_AT(Q1, mm, kk, j);
+                        for (int i = kk + 1 + part; i < mm; i += 4) wv += EKF_AT(Hq, mm, i, kk) * EKF_AT(Q1, mm, i, j);
+                    }
+                    wv += __shfl_xor(wv, 1, 64);
+                    wv += __shfl_xor(wv, 2, 64);
+                    wv *= tau[kk];
+                    if (j < N) {
+                        if (part == 0) EKF_AT(Q1, mm, kk, j) -= wv;
+                        for (int i = kk + 1 + part; i < mm; i += 4) EKF_AT(Q1, mm, i, j) -= EKF_AT(Hq, mm, i, kk) * wv;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < N * N; e += NTHREADS) { const int i = e % N, j = e / N; EKF_AT(HrG, N, i, j) = (i <= j) ? EKF_AT(Hq, mm, i, j) : 0.0; }
+            for (int j = tid; j < N; j += NTHREADS) {
+                double s = 0.0;
+                for (int i = 0; i < mm; ++i) s += EKF_AT(Q1, mm, i, j) * rq[i];
+                rn[j] = s;
+            }
+            for (int e = tid; e < mm * N; e += NTHREADS) {     // T1 = Rr thinQ
+                const int i = e % mm, j = e / mm;
+                double s = 0.0;
+                for (int p = 0; p < mm; ++p) s += EKF_AT(Rr, mm, i, p) * EKF_AT(Q1, mm, p, j);
+                EKF_AT(T1, mm, i, j) = s;
+            }
+            __syncthreads();
+            for (int e = tid; e < N * N; e += NTHREADS) {      // Rn = thinQ^T T1
+                const int i = e % N, j = e / N;
+                double s = 0.0;
+                for (int p = 0; p < mm; ++p) s += EKF_AT(Q1, mm, p, i) * EKF_AT(T1, mm, p, j);
+                EKF_AT(Rn, N, i, j) = s;
+            }
+            __syncthreads();
+            // gain phase: Hr, T2, S, K in LDS (N x N each)
+            double *Hr = lds, *T2 = Hr + (size_t)N * N, *S = T2 + (size_t)N * N, *K = S + (size_t)N * N;
+            for (int e = tid; e < N * N; e += NTHREADS) Hr[e] = HrG[e];
+            __syncthreads();
+            for (int e = tid; e < N * N; e += NTHREADS) {
+                const int i = e % N, j = e / N;
+                double t = 0.0;
+                for (int p = j; p < N; ++p) t += EKF_AT(P, N, i, p) * EKF_AT(Hr, N, j, p);
+                EKF_AT(T2, N, i, j) = t;
+            }
+            __syncthreads();
+            for (int e = tid; e < N * N; e += NTHREADS) {
+                const int i = e % N, j = e / N;
+                double s = 0.0;
+                for (int p = i; p < N; ++p) s += EKF_AT(Hr, N, i, p) * EKF_AT(T2, N, p, j);
+                EKF_AT(S, N, i, j) = s + EKF_AT(Rn, N, i, j);
+            }
+            __syncthreads();
+            ekf_cholesky<NTHREADS>(S, N, tid, &sh[3]);
+            if (sh[3] >= 0) {
+                status |= SLK_ST_SINGULAR;
+            } else {
+                for (int i = tid; i < N; i += NTHREADS) {
+                    for (int c = 0; c < N; ++c) {
+                        double s = EKF_AT(T2, N, i, c);
+                        for (int p = 0; p < c; ++p) s -= EKF_AT(S, N, c, p) * EKF_AT(K, N, i, p);
+                        EKF_AT(K, N, i, c) = s / EKF_AT(S, N, c, c);
+                    }
+                    for (int c = N - 1; c >= 0; --c) {
+                        double s = EKF_AT(K, N, i, c);
+                        for (int p = c + 1; p < N; ++p) s -= EKF_AT(S, N, p, c) * EKF_AT(K, N, i, p);
+                        EKF_AT(K, N, i, c) = s / EKF_AT(S, N, c, c);
+                    }
+                }
+                __syncthreads();
+                for (int e = tid; e < N * N; e += NTHREADS) {
+                    const int i = e % N, j = e / N;
+                    double s = 0.0;
+                    for (int p = 0; p < N; ++p) s += EKF_AT(K, N, i, p) * EKF_AT(T2, N, j, p);
+                    EKF_AT(Pn, N, i, j) = EKF_AT(P, N, i, j) - s;
+                }
+                for (int i = tid; i < N; i += NTHREADS) {
+                    double s = 0.0;
+                    for (int p = 0; p < N; ++p) s += EKF_AT(K, N, i, p) * rn[p];
+                    delta[i] = s;
+                }
+                __syncthreads();
+                for (int e = tid; e < N * N; e += NTHREADS) P[e] = Pn[e];
+                for (int blk = tid; blk <= a.k; blk += NTHREADS) {
+                    const int to = blk ? 12 + 6 * (blk - 1) : 0, so = blk ? 13 + 7 * (blk - 1) : 0;
+                    for (int c = 0; c < 3; ++c) mean[so + c] += delta[to + c];
+                    stq(mean + so + 3, qmul(ldq(mean + so + 3), so3_exp(delta[to + 3], delta[to + 4], delta[to + 5])));
+                    if (blk == 0) for (int c = 0; c < 6; ++c) mean[7 + c] += delta[6 + c];
+                }
+            }
+        }
+    }
+    if (tid == 0 && status) atomicOr(a.status + b, status);
+}
+
+// LDS doubles the resident variant needs
+__host__ __device__ inline size_t ekf_lds_doubles(int N, int m)
+{
+    size_t g = 2 * (size_t)pk_size(m), q = 2 * (size_t)m * N, k = 4 * (size_t)N * N;
+    size_t r = g > q ? g : q;
+    return r > k ? r : k;
+}
+
 } // namespace slk
