@@ -511,3 +511,31 @@ def test_msckf_ekf_update_edge_cases(slk):
     f.clear_status()
     f.update_ekf(e["z"], e["zmean"], e["H"], -np.eye(m))
     assert (f.status() & slk.ST_SINGULAR).all() and np.array_equal(f.getPk(), e["P"])
+
+
+def test_msckf_long_trajectory_stays_on_the_oracle(slk):
+    # 30 fused steps with fresh process inputs and measurements every step (a Monte-Carlo trajectory): the GPU state
+    # must track the oracle's without drift beyond the north-star tolerance (observed ~1e-12)
+    B, k, m, steps = 12, 8, 8, 30
+    s = sc.synthetic_msckf(B, k, m=m, seed=2024)
+    lay = o.layout(o.MULTI, k)
+    N = s["N"]
+    rng = np.random.default_rng(5)
+    f = slk.Msckf(s["mean"], s["P"])
+    mean, P = s["mean"].copy(), s["P"].copy()
+    tot_g, tot_o = np.zeros(B, dtype=np.int64), np.zeros(B, dtype=np.int64)
+    for t in range(steps):
+        u = s["u"].copy()
+        u[:, 0:3] += rng.normal(0, 0.02, (B, 3))
+        z = s["z"] + rng.normal(0, 0.02, s["z"].shape)
+        f.step(slk.PM_DELTA_POSE, u, s["Q"], z, slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+        tot_g += f.outliers()
+        st, out = o.msckf_step_batch(k, m, 1, mean, P, u, s["feat"], z, s["Q"], s["R"])
+        assert st == 0
+        tot_o += out
+    assert (f.status() & ~slk.ST_ALL_REJECTED == 0).all()
+    np.testing.assert_array_equal(tot_g, tot_o)
+    Pg, Mg = f.getPk(), f.muState()
+    for b in range(B):
+        assert rel(Pg[b], P[b].reshape(N, N).T) <= 1e-8, b
+        assert mean_err(lay, Mg[b], mean[b]) <= 1e-8, b
