@@ -1414,7 +1414,59 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 if (wave == 0) {
                     auto sel = [&](int i, int j) { return Sm[idx[i] + m * idx[j]]; };
                     int f0;
-                    if (mmr <= 16) {
+                    if (mmr <= 8) {
+                        // up to four 2-row blocks: every lane factors the (padded) 8x8 matrix in registers -- no LDS
+                        // round trips -- and the lanes t < N solve their row of K straight away (N <= 64: one wave)
+                        double gg[8][8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+#pragma unroll
+                            for (int j = 0; j <= i; ++j) {
+                                const bool in = i < mmr && j < mmr;
+                                const double v = Sm[in ? idx[i] + m * idx[j] : 0];
+                                gg[i][j] = in ? v : (i == j ? 1.0 : 0.0);
+                            }
+                        double gi[8];
+                        f0 = -1;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            double d = gg[j][j];
+#pragma unroll
+                            for (int p = 0; p < j; ++p) d = fma(-gg[j][p], gg[j][p], d);
+                            if (f0 < 0 && !(d > 0.0)) f0 = j;
+                            double sq, rs;
+                            rsqrt_pivot(d, sq, rs);
+                            gg[j][j] = sq;
+                            gi[j] = rs;
+#pragma unroll
+                            for (int i = j + 1; i < 8; ++i) {
+                                double v = gg[i][j];
+#pragma unroll
+                                for (int p = 0; p < j; ++p) v = fma(-gg[i][p], gg[j][p], v);
+                                gg[i][j] = v * rs;
+                            }
+                        }
+                        if (f0 < 0) {
+                            for (int t = lane; t < N; t += 64) {
+                                double x[8];
+#pragma unroll
+                                for (int c = 0; c < 8; ++c) {             // forward: Ls w = p
+                                    double sum = (c < mmr) ? Pxz[t + N * idx[c < mmr ? c : 0]] : 0.0;
+#pragma unroll
+                                    for (int p = 0; p < c; ++p) sum = fma(-gg[c][p], x[p], sum);
+                                    x[c] = sum * gi[c];
+                                }
+#pragma unroll
+                                for (int c = 7; c >= 0; --c) {            // backward: Ls^T x = w
+                                    double sum = x[c];
+#pragma unroll
+                                    for (int p = c + 1; p < 8; ++p) sum = fma(-gg[p][c], x[p], sum);
+                                    x[c] = sum * gi[c];
+                                    if (c < mmr) K[t + N * c] = x[c];
+                                }
+                            }
+                        }
+                    } else if (mmr <= 16) {
                         d4 acc[CholM<1>::NTL];
                         cholm_load<1>(acc, mmr, lane, sel);
                         f0 = cholm_factor<1>(acc, G, mmr, colbuf, lane);
@@ -1429,35 +1481,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 const int sfail = ish[46];
                 bool singular = false;
                 if (sfail < 0 && mmr <= 8) {
-                    // row-wise solve held in registers (fully unrolled for m' <= 8)
-                    double ginv[8];
-                    const double gd = (lane < mmr) ? 1.0 / G[pk(mmr, lane, lane)] : 0.0;   // one division per lane, then broadcast
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) ginv[c] = __shfl(gd, c, 64);
-                    for (int t = tid; t < N; t += NTHREADS) {
-                        double x[8];
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {                 // forward: Ls w = p
-                            x[c] = 0.0;
-                            if (c < mmr) {
-                                double sum = Pxz[t + N * idx[c]];
-#pragma unroll
-                                for (int p = 0; p < c; ++p) sum -= G[pk(mmr, c, p)] * x[p];
-                                x[c] = sum * ginv[c];
-                            }
-                        }
-#pragma unroll
-                        for (int c = 7; c >= 0; --c) {                // backward: Ls^T x = w
-                            if (c < mmr) {
-                                double sum = x[c];
-#pragma unroll
-                                for (int p = c + 1; p < 8; ++p)
-                                    if (p < mmr) sum -= G[pk(mmr, p, c)] * x[p];
-                                x[c] = sum * ginv[c];
-                                K[t + N * c] = x[c];
-                            }
-                        }
-                    }
+                    // K was solved by wave 0 above
                 } else if (sfail < 0) {
                     for (int t = tid; t < N; t += NTHREADS) {
                         for (int c = 0; c < mmr; ++c) {               // forward: Ls w = p
