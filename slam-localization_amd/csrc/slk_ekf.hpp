@@ -283,6 +283,36 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_kernel(EkfArgs a)
     if (tid == 0 && status) atomicOr(a.status + b, status);
 }
 
+// C(i, j) = sum_p A(i, p) B(p, j) on the fp64 matrix cores: 16x16 output tiles dealt to the waves, operands fetched
+// per lane through the element functors (A fragment: row l&15, k l>>4; B fragment: k l>>4, column l&15), two k-steps
+// per trip on independent accumulators.  store(row, col, value) sees every in-range element of the computed tiles.
+template <class AFn, class BFn, class StoreFn>
+__device__ __forceinline__ void ekf_mfma_gemm(int M, int Nc, int K, bool lower_only, int wave, int nwaves, int lane,
+                                              AFn Ael, BFn Bel, StoreFn store)
+{
+    const int c = lane & 15, g = lane >> 4;
+    const int ntr = (M + 15) >> 4, ntc = (Nc + 15) >> 4;
+    for (int t = wave; t < ntr * ntc; t += nwaves) {
+        const int I = t % ntr, J = t / ntr;
+        if (lower_only && I < J) continue;
+        const int r = 16 * I + c, cc = 16 * J + c;
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            const int p0 = k0 + g, p1 = k0 + 4 + g;
+            const double a0 = (r < M && p0 < K) ? Ael(r, p0) : 0.0, b0 = (cc < Nc && p0 < K) ? Bel(p0, cc) : 0.0;
+            const double a1 = (r < M && p1 < K) ? Ael(r, p1) : 0.0, b1 = (cc < Nc && p1 < K) ? Bel(p1, cc) : 0.0;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+        }
+        acc0 = acc0 + acc1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 16 * I + g + 4 * q;
+            if (row < M && cc < Nc) store(row, cc, acc0[q]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ LDS-resident variant (m <= 128, N <= 64)
 // Same steps; the two factorisations, the inverse factor, the QR sweep and thinQ live in LDS (132 KB: one workgroup
 // per CU), dots over a column are split over four threads.  Everything GEMM-shaped still reads the global workspace.
@@ -314,6 +344,8 @@ template <int NTHREADS>
 __global__ __launch_bounds__(NTHREADS) void msckf_ekf_lds_kernel(EkfArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NWV = NTHREADS / 64;
+    const int wvi = threadIdx.x >> 6, lni = threadIdx.x & 63;
     __shared__ int idx[136];
     __shared__ int sh[8];
     __shared__ double hh[4];
@@ -342,20 +374,12 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_lds_kernel(EkfArgs a)
     double *L0 = lds, *Li = lds + np;                          // gate phase: packed factor and its inverse
     if (tid == 0) { sh[0] = m; sh[1] = 0; sh[2] = -1; sh[3] = -1; a.outliers[b] = 0u; }
     for (int r = tid; r < m; r += NTHREADS) { innov[r] = z[r] - zm[r]; idx[r] = r; }
-    for (int e = tid; e < N * m; e += NTHREADS) {
-        const int i = e % N, j = e / N;
-        double s = 0.0;
-        for (int p = 0; p < N; ++p) s += EKF_AT(P, N, i, p) * EKF_AT(H, m, j, p);
-        EKF_AT(PHt, N, i, j) = s;
-    }
+    ekf_mfma_gemm(N, m, N, false, wvi, NWV, lni, [&](int i, int p) { return EKF_AT(P, N, i, p); },
+                  [&](int p, int j) { return EKF_AT(H, m, j, p); }, [&](int i, int j, double v) { EKF_AT(PHt, N, i, j) = v; });
     __syncthreads();
-    for (int e = tid; e < m * m; e += NTHREADS) {              // lower triangle of S0 = H P H^T + R
-        const int i = e % m, j = e / m;
-        if (i < j) continue;
-        double s = 0.0;
-        for (int p = 0; p < N; ++p) s += EKF_AT(H, m, i, p) * EKF_AT(PHt, N, p, j);
-        L0[pk(m, i, j)] = s + EKF_AT(R, m, i, j);
-    }
+    ekf_mfma_gemm(m, m, N, true, wvi, NWV, lni, [&](int i, int p) { return EKF_AT(H, m, i, p); },     // lower triangle of S0
+                  [&](int p, int j) { return EKF_AT(PHt, N, p, j); },
+                  [&](int i, int j, double v) { if (i >= j) L0[pk(m, i, j)] = v + EKF_AT(R, m, i, j); });
     __syncthreads();
     ekf_cholesky_packed_lds<NTHREADS>(L0, m, tid, &sh[2]);
     int status = 0;
@@ -479,37 +503,22 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_lds_kernel(EkfArgs a)
                 for (int i = 0; i < mm; ++i) s += EKF_AT(Q1, mm, i, j) * rq[i];
                 rn[j] = s;
             }
-            for (int e = tid; e < mm * N; e += NTHREADS) {     // T1 = Rr thinQ
-                const int i = e % mm, j = e / mm;
-                double s = 0.0;
-                for (int p = 0; p < mm; ++p) s += EKF_AT(Rr, mm, i, p) * EKF_AT(Q1, mm, p, j);
-                EKF_AT(T1, mm, i, j) = s;
-            }
+            ekf_mfma_gemm(mm, N, mm, false, wvi, NWV, lni, [&](int i, int p) { return EKF_AT(Rr, mm, i, p); },   // T1 = Rr thinQ
+                          [&](int p, int j) { return EKF_AT(Q1, mm, p, j); }, [&](int i, int j, double v) { EKF_AT(T1, mm, i, j) = v; });
             __syncthreads();
-            for (int e = tid; e < N * N; e += NTHREADS) {      // Rn = thinQ^T T1
-                const int i = e % N, j = e / N;
-                double s = 0.0;
-                for (int p = 0; p < mm; ++p) s += EKF_AT(Q1, mm, p, i) * EKF_AT(T1, mm, p, j);
-                EKF_AT(Rn, N, i, j) = s;
-            }
+            ekf_mfma_gemm(N, N, mm, false, wvi, NWV, lni, [&](int i, int p) { return EKF_AT(Q1, mm, p, i); },    // Rn = thinQ^T T1
+                          [&](int p, int j) { return EKF_AT(T1, mm, p, j); }, [&](int i, int j, double v) { EKF_AT(Rn, N, i, j) = v; });
             __syncthreads();
             // gain phase: Hr, T2, S, K in LDS (N x N each)
             double *Hr = lds, *T2 = Hr + (size_t)N * N, *S = T2 + (size_t)N * N, *K = S + (size_t)N * N;
             for (int e = tid; e < N * N; e += NTHREADS) Hr[e] = HrG[e];
             __syncthreads();
-            for (int e = tid; e < N * N; e += NTHREADS) {
-                const int i = e % N, j = e / N;
-                double t = 0.0;
-                for (int p = j; p < N; ++p) t += EKF_AT(P, N, i, p) * EKF_AT(Hr, N, j, p);
-                EKF_AT(T2, N, i, j) = t;
-            }
+            ekf_mfma_gemm(N, N, N, false, wvi, NWV, lni, [&](int i, int p) { return EKF_AT(P, N, i, p); },       // T2 = P Hr^T
+                          [&](int p, int j) { return EKF_AT(Hr, N, j, p); }, [&](int i, int j, double v) { EKF_AT(T2, N, i, j) = v; });
             __syncthreads();
-            for (int e = tid; e < N * N; e += NTHREADS) {
-                const int i = e % N, j = e / N;
-                double s = 0.0;
-                for (int p = i; p < N; ++p) s += EKF_AT(Hr, N, i, p) * EKF_AT(T2, N, p, j);
-                EKF_AT(S, N, i, j) = s + EKF_AT(Rn, N, i, j);
-            }
+            ekf_mfma_gemm(N, N, N, false, wvi, NWV, lni, [&](int i, int p) { return EKF_AT(Hr, N, i, p); },      // S = Hr T2 + Rn
+                          [&](int p, int j) { return EKF_AT(T2, N, p, j); },
+                          [&](int i, int j, double v) { EKF_AT(S, N, i, j) = v + EKF_AT(Rn, N, i, j); });
             __syncthreads();
             ekf_cholesky<NTHREADS>(S, N, tid, &sh[3]);
             if (sh[3] >= 0) {
@@ -528,12 +537,9 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_lds_kernel(EkfArgs a)
                     }
                 }
                 __syncthreads();
-                for (int e = tid; e < N * N; e += NTHREADS) {
-                    const int i = e % N, j = e / N;
-                    double s = 0.0;
-                    for (int p = 0; p < N; ++p) s += EKF_AT(K, N, i, p) * EKF_AT(T2, N, j, p);
-                    EKF_AT(Pn, N, i, j) = EKF_AT(P, N, i, j) - s;
-                }
+                ekf_mfma_gemm(N, N, N, false, wvi, NWV, lni, [&](int i, int p) { return EKF_AT(K, N, i, p); },   // Pk - K T2^T
+                              [&](int p, int j) { return EKF_AT(T2, N, j, p); },
+                              [&](int i, int j, double v) { EKF_AT(Pn, N, i, j) = EKF_AT(P, N, i, j) - v; });
                 for (int i = tid; i < N; i += NTHREADS) {
                     double s = 0.0;
                     for (int p = 0; p < N; ++p) s += EKF_AT(K, N, i, p) * rn[p];
