@@ -449,6 +449,9 @@ int slk_update_ekf(slk_filter *f, const double *z, const double *zmean, const do
     rc = stage_reserve(f, f->ws_ekf, B * ekf_ws_doubles(N, m));
     if (rc) return rc;
     a.ws = f->ws_ekf.p;
+#ifdef SLK_STAMPS
+    a.dbg = g_dbg;
+#endif
     const size_t lds = ekf_lds_doubles(N, m) * sizeof(double);
     if (m <= 128 && N <= 64 && lds <= 140 * 1024) {               // factorisations, QR and thinQ resident in LDS
         auto kern = msckf_ekf_lds_kernel<1024>;

@@ -25,6 +25,7 @@ struct EkfArgs {
     const double *z, *zmean, *H, *R;     // [B][m], [B][m], [B][m*N] column-major, [B or 1][m*m]
     int r_stride;
     double *ws;                          // per-filter workspace, ekf_ws_doubles(N, m) each
+    long long *dbg;                      // phase stamps [B][32], diagnostic builds only
 };
 
 __host__ __device__ inline size_t ekf_ws_doubles(int N, int m)
@@ -33,6 +34,11 @@ __host__ __device__ inline size_t ekf_ws_doubles(int N, int m)
 }
 
 #define EKF_AT(M, ld, i, j) (M)[(size_t)(j) * (ld) + (i)]
+#ifdef SLK_STAMPS
+#define EKF_STAMP(i) do { if (threadIdx.x == 0 && a.dbg) a.dbg[(size_t)blockIdx.x * 32 + (i)] = clock64(); } while (0)
+#else
+#define EKF_STAMP(i) do { } while (0)
+#endif
 
 // lower Cholesky in place (column by column, right-looking); returns through *flag the first non-positive pivot
 template <int NTHREADS>
@@ -340,6 +346,86 @@ __device__ void ekf_cholesky_packed_lds(double *A /* packed lower, column-major 
     }
 }
 
+// Blocked right-looking Cholesky on any lower-triangle accessor A(i, j) -> double& (packed or full storage, LDS):
+// panels of 16 columns are factored column by column (the rank-1 updates touch the panel's own columns only), the
+// trailing matrix gets one rank-16 update per panel on the matrix cores.
+template <int NTHREADS, class AccFn>
+__device__ __forceinline__ void ekf_cholesky_blocked(int n, int tid, int *flag, AccFn A)
+{
+    constexpr int NWV = NTHREADS / 64;
+    const int wv = tid >> 6, ln = tid & 63;
+    for (int J = 0; J < n; J += 16) {
+        const int nb = (n - J < 16) ? n - J : 16;
+        // (a) the 16 x 16 diagonal block, column by column inside ONE wave (wave-local LDS ordering, no barrier)
+        if (wv == 0) {
+            for (int jj = 0; jj < nb; ++jj) {
+                const int j = J + jj;
+                const double d = A(j, j);
+                if (!(d > 0.0)) { if (ln == 0 && *flag < 0) *flag = j; }
+                const double rs = 1.0 / sqrt(d);
+                wave_sync();
+                if (ln > jj && ln < nb) A(J + ln, j) *= rs;
+                if (ln == jj) A(j, j) = sqrt(d);
+                wave_sync();
+                const int pc = nb - jj - 1;                          // remaining columns of the block
+                for (int e = ln; e < pc * pc; e += 64) {
+                    const int c = jj + 1 + e / pc, i = jj + 1 + e % pc;
+                    if (i >= c) A(J + i, J + c) -= A(J + i, j) * A(J + c, j);
+                }
+                wave_sync();
+            }
+        }
+        __syncthreads();
+        // (b) rows below the block: X L11^T = A21, one row per thread, the row's 16 values in registers
+        const int T0 = J + nb, rem2 = n - T0;
+        for (int r = tid; r < rem2; r += NTHREADS) {
+            double x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                if (c < nb) {
+                    double v = A(T0 + r, J + c);
+#pragma unroll
+                    for (int p = 0; p < c; ++p) v -= x[p] * A(J + c, J + p);
+                    x[c] = v / A(J + c, J + c);
+                    A(T0 + r, J + c) = x[c];
+                } else {
+                    x[c] = 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        // (c) trailing matrix: one rank-16 update on the matrix cores
+        if (rem2 > 0) {
+            ekf_mfma_gemm(rem2, rem2, nb, true, wv, NWV, ln, [&](int i, int p) { return A(T0 + i, J + p); },
+                          [&](int p, int c) { return A(T0 + c, J + p); },
+                          [&](int i, int c, double v) { if (i >= c) A(T0 + i, T0 + c) -= v; });
+            __syncthreads();
+        }
+    }
+}
+
+// Inverse of a lower-triangular factor, row by row: row i of L^-1 is -(1 / L_ii) * L(i, 0..i-1) * L^-1(0..i-1, :) --
+// every column is an independent dot product, G lanes each, one workgroup barrier per row.
+template <int NTHREADS, class LFn, class RdFn, class WrFn>
+__device__ __forceinline__ void ekf_inverse_lower(int n, int tid, LFn Lel, RdFn rd, WrFn wr)
+{
+    constexpr int G = 8, CPP = NTHREADS / G;
+    const int sub = tid % G, cl = tid / G;
+    for (int i = 0; i < n; ++i) {
+        const double rinv = 1.0 / Lel(i, i);
+        for (int c0 = 0; c0 <= i; c0 += CPP) {
+            const int c = c0 + cl;
+            double sacc = 0.0;
+            if (c < i) for (int p = c + sub; p < i; p += G) sacc += Lel(i, p) * rd(p, c);
+            sacc += __shfl_xor(sacc, 1, 64);
+            sacc += __shfl_xor(sacc, 2, 64);
+            sacc += __shfl_xor(sacc, 4, 64);
+            if (sub == 0 && c <= i) wr(i, c, (c == i) ? rinv : -sacc * rinv);
+        }
+        __syncthreads();
+    }
+}
+
 template <int NTHREADS>
 __global__ __launch_bounds__(NTHREADS) void msckf_ekf_lds_kernel(EkfArgs a)
 {
@@ -373,6 +459,7 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_lds_kernel(EkfArgs a)
     const int np = pk_size(m);
     double *L0 = lds, *Li = lds + np;                          // gate phase: packed factor and its inverse
     if (tid == 0) { sh[0] = m; sh[1] = 0; sh[2] = -1; sh[3] = -1; a.outliers[b] = 0u; }
+    EKF_STAMP(0);
     for (int r = tid; r < m; r += NTHREADS) { innov[r] = z[r] - zm[r]; idx[r] = r; }
     ekf_mfma_gemm(N, m, N, false, wvi, NWV, lni, [&](int i, int p) { return EKF_AT(P, N, i, p); },
                   [&](int p, int j) { return EKF_AT(H, m, j, p); }, [&](int i, int j, double v) { EKF_AT(PHt, N, i, j) = v; });
@@ -381,20 +468,17 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_lds_kernel(EkfArgs a)
                   [&](int p, int j) { return EKF_AT(PHt, N, p, j); },
                   [&](int i, int j, double v) { if (i >= j) L0[pk(m, i, j)] = v + EKF_AT(R, m, i, j); });
     __syncthreads();
-    ekf_cholesky_packed_lds<NTHREADS>(L0, m, tid, &sh[2]);
+    EKF_STAMP(1);
+    ekf_cholesky_blocked<NTHREADS>(m, tid, &sh[2], [&](int i, int j) -> double & { return L0[pk(m, i, j)]; });
+    EKF_STAMP(2);
     int status = 0;
     if (sh[2] >= 0) {
         status |= SLK_ST_SINGULAR;
     } else {
-        for (int c = tid; c < m; c += NTHREADS) {              // Li = L0^-1, one column per thread
-            const int cb = pk(m, c, c) - c;                    // Li(i, c) = Li[cb + i]
-            for (int i = c; i < m; ++i) {
-                double s = (i == c) ? 1.0 : 0.0;
-                for (int p = c; p < i; ++p) s -= L0[pk(m, i, p)] * Li[cb + p];
-                Li[cb + i] = s / L0[pk(m, i, i)];
-            }
-        }
-        __syncthreads();
+        ekf_inverse_lower<NTHREADS>(m, tid, [&](int i, int p) { return L0[pk(m, i, p)]; },       // Li = L0^-1
+                                    [&](int p, int c) { return Li[pk(m, p, c)]; },
+                                    [&](int i, int c, double v) { Li[pk(m, i, c)] = v; });
+        EKF_STAMP(3);
         for (int e = tid; e < 3 * (m / 2); e += NTHREADS) {    // the 2x2 diagonal blocks of the information matrix
             const int blk = e / 3, q = e % 3, r = 2 * blk + (q == 2), c = 2 * blk + (q >= 1);
             double s = 0.0;
@@ -427,6 +511,7 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_lds_kernel(EkfArgs a)
         }
         __syncthreads();
         const int mm = sh[0];
+        EKF_STAMP(4);
         if (mm > 0 && mm < N) {
             status |= SLK_ST_EKF_ROWS;
         } else if (mm > 0) {
@@ -435,7 +520,9 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_lds_kernel(EkfArgs a)
             for (int e = tid; e < mm * mm; e += NTHREADS) { const int i = e % mm, j = e / mm; EKF_AT(Rr, mm, i, j) = EKF_AT(R, m, idx[i], idx[j]); }
             for (int i = tid; i < mm; i += NTHREADS) rq[i] = innov[idx[i]];
             __syncthreads();
-            const int col4 = tid >> 2, part = tid & 3;         // four threads per column
+            EKF_STAMP(5);
+            constexpr int G = 16, CPP = NTHREADS / G;          // sixteen lanes per column
+            const int colg = tid / G, part = tid % G;
             for (int kk = 0; kk < N; ++kk) {
                 if (tid < 64) {                                // tail norm of column kk by one wave
                     double part2 = 0.0;
@@ -460,43 +547,49 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_lds_kernel(EkfArgs a)
                 for (int i = kk + 1 + tid; i < mm; i += NTHREADS) EKF_AT(Hq, mm, i, kk) = (den != 0.0) ? EKF_AT(Hq, mm, i, kk) / den : 0.0;
                 if (tid == 0) EKF_AT(Hq, mm, kk, kk) = hh[0];
                 __syncthreads();
-                for (int j0 = kk + 1; j0 < N; j0 += NTHREADS / 4) {
-                    const int j = j0 + col4;
+                for (int j0 = kk + 1; j0 < N; j0 += CPP) {
+                    const int j = j0 + colg;
                     double wv = 0.0;
                     if (j < N) {
                         if (part == 0) wv = EKF_AT(Hq, mm, kk, j);
-                        for (int i = kk + 1 + part; i < mm; i += 4) wv += EKF_AT(Hq, mm, i, kk) * EKF_AT(Hq, mm, i, j);
+                        for (int i = kk + 1 + part; i < mm; i += G) wv += EKF_AT(Hq, mm, i, kk) * EKF_AT(Hq, mm, i, j);
                     }
                     wv += __shfl_xor(wv, 1, 64);
                     wv += __shfl_xor(wv, 2, 64);
+                    wv += __shfl_xor(wv, 4, 64);
+                    wv += __shfl_xor(wv, 8, 64);
                     wv *= tk;
                     if (j < N) {
                         if (part == 0) EKF_AT(Hq, mm, kk, j) -= wv;
-                        for (int i = kk + 1 + part; i < mm; i += 4) EKF_AT(Hq, mm, i, j) -= EKF_AT(Hq, mm, i, kk) * wv;
+                        for (int i = kk + 1 + part; i < mm; i += G) EKF_AT(Hq, mm, i, j) -= EKF_AT(Hq, mm, i, kk) * wv;
                     }
                 }
                 __syncthreads();
             }
-            // thinQ: four threads per column, reflectors in reverse; a column is private to its four threads
-            for (int j0 = 0; j0 < N; j0 += NTHREADS / 4) {
-                const int j = j0 + col4;
-                if (j < N) for (int i = part; i < mm; i += 4) EKF_AT(Q1, mm, i, j) = (i == j) ? 1.0 : 0.0;
+            EKF_STAMP(6);
+            // thinQ: sixteen lanes (of one wave) per column, reflectors in reverse; a column is private to its lanes
+            for (int j0 = 0; j0 < N; j0 += CPP) {
+                const int j = j0 + colg;
+                if (j < N) for (int i = part; i < mm; i += G) EKF_AT(Q1, mm, i, j) = (i == j) ? 1.0 : 0.0;
                 for (int kk = N - 1; kk >= 0; --kk) {
                     double wv = 0.0;
                     if (j < N) {
                         if (part == 0) wv = EKF_AT(Q1, mm, kk, j);
-                        for (int i = kk + 1 + part; i < mm; i += 4) wv += EKF_AT(Hq, mm, i, kk) * EKF_AT(Q1, mm, i, j);
+                        for (int i = kk + 1 + part; i < mm; i += G) wv += EKF_AT(Hq, mm, i, kk) * EKF_AT(Q1, mm, i, j);
                     }
                     wv += __shfl_xor(wv, 1, 64);
                     wv += __shfl_xor(wv, 2, 64);
+                    wv += __shfl_xor(wv, 4, 64);
+                    wv += __shfl_xor(wv, 8, 64);
                     wv *= tau[kk];
                     if (j < N) {
                         if (part == 0) EKF_AT(Q1, mm, kk, j) -= wv;
-                        for (int i = kk + 1 + part; i < mm; i += 4) EKF_AT(Q1, mm, i, j) -= EKF_AT(Hq, mm, i, kk) * wv;
+                        for (int i = kk + 1 + part; i < mm; i += G) EKF_AT(Q1, mm, i, j) -= EKF_AT(Hq, mm, i, kk) * wv;
                     }
                 }
             }
             __syncthreads();
+            EKF_STAMP(7);
             for (int e = tid; e < N * N; e += NTHREADS) { const int i = e % N, j = e / N; EKF_AT(HrG, N, i, j) = (i <= j) ? EKF_AT(Hq, mm, i, j) : 0.0; }
             for (int j = tid; j < N; j += NTHREADS) {
                 double s = 0.0;
@@ -509,6 +602,7 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_lds_kernel(EkfArgs a)
             ekf_mfma_gemm(N, N, mm, false, wvi, NWV, lni, [&](int i, int p) { return EKF_AT(Q1, mm, p, i); },    // Rn = thinQ^T T1
                           [&](int p, int j) { return EKF_AT(T1, mm, p, j); }, [&](int i, int j, double v) { EKF_AT(Rn, N, i, j) = v; });
             __syncthreads();
+            EKF_STAMP(8);
             // gain phase: Hr, T2, S, K in LDS (N x N each)
             double *Hr = lds, *T2 = Hr + (size_t)N * N, *S = T2 + (size_t)N * N, *K = S + (size_t)N * N;
             for (int e = tid; e < N * N; e += NTHREADS) Hr[e] = HrG[e];
@@ -520,29 +614,33 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_lds_kernel(EkfArgs a)
                           [&](int p, int j) { return EKF_AT(T2, N, p, j); },
                           [&](int i, int j, double v) { EKF_AT(S, N, i, j) = v + EKF_AT(Rn, N, i, j); });
             __syncthreads();
-            ekf_cholesky<NTHREADS>(S, N, tid, &sh[3]);
+            EKF_STAMP(9);
+            ekf_cholesky_blocked<NTHREADS>(N, tid, &sh[3], [&](int i, int j) -> double & { return EKF_AT(S, N, i, j); });
+            EKF_STAMP(10);
             if (sh[3] >= 0) {
                 status |= SLK_ST_SINGULAR;
             } else {
-                for (int i = tid; i < N; i += NTHREADS) {
-                    for (int c = 0; c < N; ++c) {
-                        double s = EKF_AT(T2, N, i, c);
-                        for (int p = 0; p < c; ++p) s -= EKF_AT(S, N, c, p) * EKF_AT(K, N, i, p);
-                        EKF_AT(K, N, i, c) = s / EKF_AT(S, N, c, c);
-                    }
-                    for (int c = N - 1; c >= 0; --c) {
-                        double s = EKF_AT(K, N, i, c);
-                        for (int p = c + 1; p < N; ++p) s -= EKF_AT(S, N, p, c) * EKF_AT(K, N, i, p);
-                        EKF_AT(K, N, i, c) = s / EKF_AT(S, N, c, c);
-                    }
-                }
+                // K = T2 S^-1 = (T2 Ls^-T) Ls^-1: the inverse factor row by row, then two products on the matrix cores.
+                // Slots: Hr (dead) takes Ls^-1, K takes Y = T2 Ls^-T, S (dead once inverted) takes the final K.
+                double *Lsi = Hr, *Y = K, *Kf = S;
+                ekf_inverse_lower<NTHREADS>(N, tid, [&](int i, int p) { return EKF_AT(S, N, i, p); },
+                                            [&](int p, int c) { return EKF_AT(Lsi, N, p, c); },
+                                            [&](int i, int c, double v) { EKF_AT(Lsi, N, i, c) = v; });
+                ekf_mfma_gemm(N, N, N, false, wvi, NWV, lni, [&](int i, int p) { return EKF_AT(T2, N, i, p); },       // Y = T2 Ls^-T
+                              [&](int p, int j) { return (p <= j) ? EKF_AT(Lsi, N, j, p) : 0.0; },
+                              [&](int i, int j, double v) { EKF_AT(Y, N, i, j) = v; });
                 __syncthreads();
-                ekf_mfma_gemm(N, N, N, false, wvi, NWV, lni, [&](int i, int p) { return EKF_AT(K, N, i, p); },   // Pk - K T2^T
+                ekf_mfma_gemm(N, N, N, false, wvi, NWV, lni, [&](int i, int p) { return EKF_AT(Y, N, i, p); },        // K = Y Ls^-1
+                              [&](int p, int j) { return (p >= j) ? EKF_AT(Lsi, N, p, j) : 0.0; },
+                              [&](int i, int j, double v) { EKF_AT(Kf, N, i, j) = v; });
+                __syncthreads();
+                EKF_STAMP(11);
+                ekf_mfma_gemm(N, N, N, false, wvi, NWV, lni, [&](int i, int p) { return EKF_AT(Kf, N, i, p); },  // Pk - K T2^T
                               [&](int p, int j) { return EKF_AT(T2, N, j, p); },
                               [&](int i, int j, double v) { EKF_AT(Pn, N, i, j) = EKF_AT(P, N, i, j) - v; });
                 for (int i = tid; i < N; i += NTHREADS) {
                     double s = 0.0;
-                    for (int p = 0; p < N; ++p) s += EKF_AT(K, N, i, p) * rn[p];
+                    for (int p = 0; p < N; ++p) s += EKF_AT(Kf, N, i, p) * rn[p];
                     delta[i] = s;
                 }
                 __syncthreads();
@@ -556,6 +654,7 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_lds_kernel(EkfArgs a)
             }
         }
     }
+    EKF_STAMP(12);
     if (tid == 0 && status) atomicOr(a.status + b, status);
 }
 
