@@ -1254,9 +1254,9 @@ struct MfmaTiles32 {
 // ------------------------------------------------------------------ the Msckf step kernel
 // predict (optional) + UKF update with applyDelta (optional), one workgroup per filter.
 template <int NT, int NTHREADS>
-__global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? SLK_WGS : (NTHREADS >= 256 && NT <= 5 ? 3 : ((NT == 6 || NT == 8) ? 2 : (NT <= 2 ? 4 : 1))))) void msckf_step_kernel(KArgs a)
+__global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? SLK_WGS : (NT == 5 ? 3 : ((NT >= 6 && NT <= 8) ? 2 : (NT <= 2 ? 4 : 1))))) void msckf_step_kernel(KArgs a)
 {
-    constexpr bool BIG = NT > 6;                           // large state: factor + rotation store in the global workspace
+    constexpr bool BIG = NT > 5;                           // large state: factor + rotation store in the global workspace
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NTHREADS / 64;
     constexpr int GD = Grid<NTHREADS>::GD;
