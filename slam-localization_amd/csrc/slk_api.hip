@@ -44,7 +44,7 @@ struct slk_filter {
     int *d_status;
     unsigned *d_outliers;
     Stage st_u, st_Q, st_mp, st_z, st_R, st_X, st_Z, st_tmpP, st_tmpM;
-    Stage ws_L, ws_DR;            // large-state workspaces (N > 96), allocated on first use
+    Stage ws_L, ws_DR;            // large-state workspaces (N > 80), allocated on first use
     Stage ws_ekf;                 // EKF update workspace, allocated on first use
     unsigned long long *d_rtab = nullptr;   // Msckf rotation-item descriptors of the current layout
     int rtab_k = -1;

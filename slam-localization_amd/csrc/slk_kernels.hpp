@@ -38,7 +38,7 @@ struct KArgs {
     // tier B sigma-point emission: 1 = predict sigma points, 2 = update sigma points
     int emit; double *Xout;
     int rebuild_prec;     // covariance rebuild arithmetic: 0 = fp64 (parity path), 1 = fp32 MFMA, 2 = bf16 inputs / fp32 accumulate
-    double *wsL, *wsDR;   // global workspaces of the large-state path (N > 96): packed factor, rotation deviations
+    double *wsL, *wsDR;   // global workspaces of the large-state path (N > 80): packed factor, rotation deviations
     const unsigned long long *rtab;   // Msckf: descriptors of the rotation items (layout only, built by the host)
     long long *dbg;   // phase stamps, diagnostic builds (-DSLK_STAMPS) only; always null in the product
     int stop;         // diagnostic builds: leave the kernel after this stamp (per-phase instruction counts)
@@ -124,7 +124,7 @@ struct Carve {
     int S, LDD, TN, W;   // W = rotation-row items that differ from X_0 (sum over blocks of rot_count)
 };
 
-// big = large-state variant (NT > 6): the packed factor and the rotation deviations live in a global
+// big = large-state variant (NT > 5, i.e. N > 80): the packed factor and the rotation deviations live in a global
 // workspace, LDS keeps the small vectors, the measurement arrays, a Cholesky panel and the MFMA panels
 __host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT, bool big = false, int prec = 0)
 {
@@ -657,7 +657,7 @@ __device__ __forceinline__ int cholw_factor(d4 (&acc)[NT], double *Lp, int n, do
 }
 
 // ------------------------------------------------------------------ blocked Cholesky on a packed factor in memory
-// Large states (N > 96): the factor does not fit registers or LDS, it lives (packed, lower) in a
+// Large states (N > 80): the factor does not fit registers or LDS, it lives (packed, lower) in a
 // global workspace that stays in L2 / Infinity Cache.  Left-looking, 16 columns per block step:
 //   1. panel = A[:, J] - L[:, 0:J] L[J, 0:J]^T   one MFMA chain per row tile, fragments read from the
 //      already finished columns in memory, result to an LDS panel ((n - 16J) x 16, ld 17)
