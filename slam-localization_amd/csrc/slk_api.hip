@@ -234,8 +234,8 @@ static int launch_msckf(slk_filter *f, const KArgs &a)
     case 5: return launch_msckf_inst<5, 256>(f, a);
     case 6: return launch_msckf_inst<6, 256>(f, a);
     case 7: case 8: return launch_msckf_inst<8, 256>(f, a);
-    case 9: case 10: return launch_msckf_inst<10, 256>(f, a);
-    case 11: case 12: case 13: return launch_msckf_inst<13, 256>(f, a);
+    case 9: case 10: return launch_msckf_inst<10, 512>(f, a);
+    case 11: case 12: case 13: return launch_msckf_inst<13, 512>(f, a);
     default: g_err = "state dimension above 208 is not supported by this build"; return SLK_E_UNSUPPORTED;
     }
 }
