@@ -74,8 +74,8 @@ def test_msckf_batch_golden_with_outliers(slk):
         assert mean_err(lay, M[b], g["mean"][b]) <= TOL, b
 
 
-@pytest.mark.parametrize("k,m,B", [(0, 2, 96), (1, 2, 96), (3, 6, 64), (8, 8, 64), (12, 8, 16), (14, 8, 6), (15, 8, 6),
-                                   (31, 8, 5)])
+@pytest.mark.parametrize("k,m,B", [(0, 2, 96), (1, 2, 96), (3, 6, 64), (8, 8, 64), (10, 8, 8), (12, 8, 16), (13, 8, 6),
+                                   (14, 8, 6), (15, 8, 6), (19, 8, 4), (24, 8, 4), (31, 8, 5)])
 def test_msckf_step_against_oracle(slk, k, m, B):
     s = sc.synthetic_msckf(B, k, m=m, seed=100 + k)
     lay = o.layout(o.MULTI, k)
