@@ -60,8 +60,11 @@ enum {
     SLK_ST_MEAN_NOT_CONVERGED = 2,  /* manifold mean hit max_it = 10000 (Msckf.hpp:475,489-493) */
     SLK_ST_SINGULAR = 4,            /* innovation covariance not invertible */
     SLK_ST_ALL_REJECTED = 8,        /* every measurement block failed the gate: update skipped (Msckf.hpp:250) */
-    SLK_ST_EKF_ROWS = 16            /* EKF update: fewer rows than state dimensions survive the gate; the reference would
+    SLK_ST_EKF_ROWS = 16,           /* EKF update: fewer rows than state dimensions survive the gate; the reference would
                                        read R.block(0,0,N,N) out of range (Msckf.hpp:806): update skipped */
+    SLK_ST_BAD_INDEX = 32           /* a pose index among the parameters of a registered measurement model is outside
+                                       0..k (Msckf) / 0..2 (Usckf) or not a number: update skipped (device-resident
+                                       parameters; host-resident ones are rejected with SLK_E_INVALID before the launch) */
 };
 
 /* cloning modes of Usckf (Usckf.hpp:37-42) */
@@ -171,6 +174,14 @@ int slk_msckf_resize(slk_filter *f, int n_clones);
  *     the pose's (J P J^T, J = [I; E_pose]); drop_clone removes clone `index` (0 = oldest) with its 6 rows / columns. */
 int slk_msckf_clone_pose(slk_filter *f);
 int slk_msckf_drop_clone(slk_filter *f, int index);
+
+/* ---- checkSigmaPoints(): Msckf.hpp:819-839 (Usckf.hpp:769-789 is the same self test).  Re-draws the sigma points of
+ *      (mu_state, Pk), takes their manifold mean and covariance on the device and reports per filter
+ *      max_cov_err [B] = max |covSigmaPoints - Pk| (the reference asserts <= 1e-6) and mean_err [B] = |mu_state [-] muX|
+ *      (the reference asserts mu_state == muX, i.e. isZero(1e-12) of the difference, MtkWrap.hpp:108-112).
+ *      The filter is not modified.  Msckf only (the Usckf facade runs the same test on the sigma points of
+ *      slk_update_sigma_points). ---- */
+int slk_check_sigma_points(slk_filter *f, double *max_cov_err, double *mean_err, int where);
 
 /* ---- arithmetic of the covariance rebuild (Msckf.hpp:665 -> :574-589): SLK_PREC_F64 (default, the
  *      parity path), SLK_PREC_F32 (fp32 MFMA) or SLK_PREC_BF16 (bf16 operands, fp32 accumulation).

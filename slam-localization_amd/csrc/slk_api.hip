@@ -7,7 +7,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/slk.h"
@@ -40,7 +43,9 @@ struct slk_filter {
     hipStream_t stream;
     bool own_stream;
     double *d_mean, *d_P;
-    size_t cap_mean, cap_P;       // capacities in doubles (per batch), so resizes can stay in place
+    size_t cap_mean, cap_P;       // capacities of d_mean / d_P in doubles (whole batch)
+    double *d_mean_alt = nullptr, *d_P_alt = nullptr;   // second pair of state buffers: layout changes (window push / pop,
+    size_t cap_mean_alt = 0, cap_P_alt = 0;             // setMeasurement) are built into it on the stream and swapped in
     int *d_status;
     unsigned *d_outliers;
     Stage st_u, st_Q, st_mp, st_z, st_R, st_X, st_Z, st_tmpP, st_tmpM;
@@ -118,17 +123,17 @@ int slk_create(const slk_config *cfg, slk_filter **out)
     f->d_mean = f->d_P = nullptr;
     f->d_status = nullptr; f->d_outliers = nullptr;
     size_t B = (size_t)f->B;
-    f->cap_mean = (size_t)f->lay.Nq; f->cap_P = (size_t)f->lay.N * f->lay.N;
-    bool ok = hipMalloc(&f->d_mean, B * f->cap_mean * sizeof(double)) == hipSuccess
-           && hipMalloc(&f->d_P, B * f->cap_P * sizeof(double)) == hipSuccess
+    f->cap_mean = B * (size_t)f->lay.Nq; f->cap_P = B * (size_t)f->lay.N * f->lay.N;
+    bool ok = hipMalloc(&f->d_mean, f->cap_mean * sizeof(double)) == hipSuccess
+           && hipMalloc(&f->d_P, f->cap_P * sizeof(double)) == hipSuccess
            && hipMalloc(&f->d_status, B * sizeof(int)) == hipSuccess
            && hipMalloc(&f->d_outliers, B * sizeof(unsigned)) == hipSuccess
            && hipEventCreate(&f->ev0) == hipSuccess && hipEventCreate(&f->ev1) == hipSuccess;
     if (!ok) { g_err = "device allocation failed"; slk_destroy(f); return SLK_E_NOMEM; }
     (void)hipMemsetAsync(f->d_status, 0, B * sizeof(int), f->stream);
     (void)hipMemsetAsync(f->d_outliers, 0, B * sizeof(unsigned), f->stream);
-    (void)hipMemsetAsync(f->d_mean, 0, B * f->cap_mean * sizeof(double), f->stream);
-    (void)hipMemsetAsync(f->d_P, 0, B * f->cap_P * sizeof(double), f->stream);
+    (void)hipMemsetAsync(f->d_mean, 0, f->cap_mean * sizeof(double), f->stream);
+    (void)hipMemsetAsync(f->d_P, 0, f->cap_P * sizeof(double), f->stream);
     *out = f;
     return SLK_OK;
 }
@@ -144,6 +149,8 @@ void slk_destroy(slk_filter *f)
     if (f->d_rtab) (void)hipFree(f->d_rtab);
     if (f->d_mean) (void)hipFree(f->d_mean);
     if (f->d_P) (void)hipFree(f->d_P);
+    if (f->d_mean_alt) (void)hipFree(f->d_mean_alt);
+    if (f->d_P_alt) (void)hipFree(f->d_P_alt);
     if (f->d_status) (void)hipFree(f->d_status);
     if (f->d_outliers) (void)hipFree(f->d_outliers);
     (void)hipEventDestroy(f->ev0);
@@ -184,6 +191,22 @@ int slk_get_state(slk_filter *f, double *mean, double *P, int where)
 
 } // extern "C"
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the function object of ONE device: remember what was
+// configured per (kernel, device) -- a process may own handles on several GPUs (slk_config.device) and launch from
+// several host threads.
+static int ensure_dynamic_lds(const void *kern, int device, size_t lds)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> configured;
+    std::lock_guard<std::mutex> guard(mu);
+    size_t &have = configured[std::make_pair(kern, device)];
+    if (lds > have) {
+        HIPCHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        have = lds;
+    }
+    return SLK_OK;
+}
+
 // ---------------------------------------------------------------------------- launch helpers
 template <int NT, int NTHREADS>
 static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
@@ -213,11 +236,8 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
     size_t lds = (size_t)cv.total * sizeof(double);
     if (lds > 160 * 1024) { g_err = "state too large for the LDS-resident kernel"; return SLK_E_UNSUPPORTED; }
     auto kern = msckf_step_kernel<NT, NTHREADS>;
-    static size_t configured = 0;
-    if (lds > configured) {
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), f->cfg.device, lds);
+    if (rc_lds) return rc_lds;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(NTHREADS), lds, f->stream, a);
     HIPCHECK(hipGetLastError());
     return SLK_OK;
@@ -247,11 +267,8 @@ static int launch_usckf_inst(slk_filter *f, const KArgs &a)
     size_t lds = (size_t)cv.total * sizeof(double);
     if (lds > 160 * 1024) { g_err = "state too large for the LDS-resident kernel"; return SLK_E_UNSUPPORTED; }
     auto kern = usckf_kernel<NT, 256>;
-    static size_t configured = 0;
-    if (lds > configured) {
-        HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), f->cfg.device, lds);
+    if (rc_lds) return rc_lds;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds, f->stream, a);
     HIPCHECK(hipGetLastError());
     return SLK_OK;
@@ -327,6 +344,19 @@ static int fill_update(slk_filter *f, KArgs &a, int model, const double *params,
     }
     int np = mm_params(model, m);
     if (np && (!params || (p_stride != 0 && p_stride < np))) return SLK_E_INVALID;
+    if (np && where == SLK_HOST) {
+        // pose indices are caller data: reject anything outside 0..k (Msckf) / 0..2 (Usckf) before it reaches a kernel
+        // (device-resident parameters are checked by the kernel itself: SLK_ST_BAD_INDEX)
+        const double maxc = f->lay.kind == SLK_MSCKF ? (double)f->lay.k : 2.0;
+        const int rows = p_stride ? f->B : 1;
+        for (int b = 0; b < rows; ++b) {
+            const double *row = params + (size_t)b * p_stride;
+            if (model == SLK_MM_FEATURE_PROJ) {
+                for (int q = 0; q < m / 2; ++q)
+                    if (!(row[4 * q + 3] >= 0.0 && row[4 * q + 3] <= maxc)) { g_err = "pose index of a feature out of range"; return SLK_E_INVALID; }
+            } else if (!(row[0] >= 0.0 && row[0] <= maxc)) { g_err = "pose index out of range"; return SLK_E_INVALID; }
+        }
+    }
     a.do_update = 1; a.mm = model; a.m = m; a.gate = gate; a.mp_stride = p_stride; a.r_stride = r_stride;
     int rc = np ? stage_in(f, f->st_mp, params, p_stride ? (size_t)f->B * p_stride : (size_t)np, where, &a.mp) : SLK_OK;
     if (rc) return rc;
@@ -365,6 +395,44 @@ __global__ void msckf_window_kernel(const double *mean, const double *P, double 
         else ssrc = e < 13 + 7 * idx ? e : e + 7;
         mo[e] = m[ssrc];
     }
+}
+
+// checkSigmaPoints (Msckf.hpp:819-839), second half: compare the re-drawn mean / covariance with the filter's own.
+// One workgroup per filter; res [2][B] = max |Pktest - Pk|, |mu_state [-] muX|.
+__global__ void check_compare_kernel(Lay L, const double *mean, const double *P, const double *mean2, const double *P2, int B,
+                                     double *res)
+{
+    __shared__ double red[256];
+    const int b = blockIdx.x, tid = threadIdx.x, N = L.N, Nq = L.Nq;
+    const double *p = P + (size_t)b * N * N, *p2 = P2 + (size_t)b * N * N;
+    const double *m = mean + (size_t)b * Nq, *m2 = mean2 + (size_t)b * Nq;
+    double e = 0.0;
+    for (int i = tid; i < N * N; i += 256) { double d = fabs(p2[i] - p[i]); e = (d > e || d != d) ? d : e; }
+    red[tid] = e;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { double o = red[tid + s]; if (o > red[tid] || o != o) red[tid] = o; }
+        __syncthreads();
+    }
+    const double cov_err = red[0];
+    __syncthreads();
+    double n2 = 0.0;
+    for (int t = tid; t < N; t += 256) {
+        int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
+        if (s >= 0) { double d = m[s] - m2[s]; n2 += d * d; }
+        else if (comp == 0) {
+            double dx, dy, dz;
+            so3_boxminus(ldq(m + so3_soff(L, blk)), ldq(m2 + so3_soff(L, blk)), dx, dy, dz);
+            n2 += dx * dx + dy * dy + dz * dz;
+        }
+    }
+    red[tid] = n2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) { res[b] = cov_err; res[B + b] = sqrt(red[0]); }
 }
 
 // DeadReckon::updatePose delta poses of a batch (src/core/DeadReckon.hpp:129-239): one thread per filter
@@ -455,11 +523,8 @@ int slk_update_ekf(slk_filter *f, const double *z, const double *zmean, const do
     const size_t lds = ekf_lds_doubles(N, m) * sizeof(double);
     if (m <= 128 && N <= 64 && lds <= 140 * 1024) {               // factorisations, QR and thinQ resident in LDS
         auto kern = msckf_ekf_lds_kernel<1024>;
-        static size_t configured = 0;
-        if (lds > configured) {
-            HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            configured = lds;
-        }
+        rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), f->cfg.device, lds);
+        if (rc) return rc;
         hipLaunchKernelGGL(kern, dim3(f->B), dim3(1024), lds, f->stream, a);
     } else {
         hipLaunchKernelGGL(msckf_ekf_kernel<256>, dim3(f->B), dim3(256), 0, f->stream, a);
@@ -624,6 +689,36 @@ int slk_usckf_cloning(slk_filter *f, int mode)
     return SLK_OK;
 }
 
+// The second pair of state buffers (layout changes are built into it, then the pairs swap): make it hold at least
+// need_mean / need_P doubles.  Grows with headroom so that a sliding window does not come back here; a hipMalloc
+// happens only then.  Nothing of the handle is changed on failure.
+static int reserve_alt(slk_filter *f, size_t need_mean, size_t need_P)
+{
+    if (f->cap_mean_alt < need_mean) {
+        if (f->d_mean_alt) HIPCHECK(hipFree(f->d_mean_alt));        // (hipFree waits for work that still reads it)
+        f->d_mean_alt = nullptr; f->cap_mean_alt = 0;
+        const size_t want = need_mean + need_mean / 2;
+        HIPCHECK(hipMalloc(&f->d_mean_alt, want * sizeof(double)));
+        f->cap_mean_alt = want;
+    }
+    if (f->cap_P_alt < need_P) {
+        if (f->d_P_alt) HIPCHECK(hipFree(f->d_P_alt));
+        f->d_P_alt = nullptr; f->cap_P_alt = 0;
+        const size_t want = need_P + need_P / 2;
+        HIPCHECK(hipMalloc(&f->d_P_alt, want * sizeof(double)));
+        f->cap_P_alt = want;
+    }
+    return SLK_OK;
+}
+
+static void swap_state_buffers(slk_filter *f)
+{
+    std::swap(f->d_mean, f->d_mean_alt);
+    std::swap(f->d_P, f->d_P_alt);
+    std::swap(f->cap_mean, f->cap_mean_alt);
+    std::swap(f->cap_P, f->cap_P_alt);
+}
+
 int slk_usckf_set_measurement(slk_filter *f, int mode, const double *z, int n, const double *R, int where)
 {
     if (!f || f->lay.kind != SLK_USCKF || !z || !R || n < 1) return SLK_E_INVALID;
@@ -632,25 +727,22 @@ int slk_usckf_set_measurement(slk_filter *f, int mode, const double *z, int n, c
     Lay oldL = f->lay;
     int nfk = mode == SLK_STATEK ? n : oldL.nfk, nfkl = mode == SLK_STATEK_L ? n : oldL.nfkl;
     Lay newL = make_lay(SLK_USCKF, 0, nfk, nfkl);
+    if (newL.N > 96) { g_err = "Usckf state dimension above 96 is not supported by this build"; return SLK_E_UNSUPPORTED; }
     size_t B = (size_t)f->B;
     const double *dz, *dR;
     int rc = stage_in(f, f->st_z, z, B * n, where, &dz);
     if (rc) return rc;
     rc = stage_in(f, f->st_R, R, (size_t)n * n, where, &dR);
     if (rc) return rc;
-    // build the new arrays out of place, then swap
-    double *nm = nullptr, *nP = nullptr;
-    HIPCHECK(hipMalloc(&nm, B * newL.Nq * sizeof(double)));
-    HIPCHECK(hipMalloc(&nP, B * (size_t)newL.N * newL.N * sizeof(double)));
+    // built out of place into the second buffer pair on the stream, then the pairs swap: no allocation in the steady
+    // state, no host synchronisation
+    rc = reserve_alt(f, B * newL.Nq, B * (size_t)newL.N * newL.N);
+    if (rc) return rc;
     int total = f->B * newL.N * newL.N;
     hipLaunchKernelGGL(usckf_set_measurement_kernel, dim3((total + 255) / 256), dim3(256), 0, f->stream,
-                       f->d_mean, f->d_P, nm, nP, dz, dR, f->B, oldL.nfk, oldL.nfkl, nfk, nfkl, mode, n);
+                       f->d_mean, f->d_P, f->d_mean_alt, f->d_P_alt, dz, dR, f->B, oldL.nfk, oldL.nfkl, nfk, nfkl, mode, n);
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipStreamSynchronize(f->stream));
-    HIPCHECK(hipFree(f->d_mean));
-    HIPCHECK(hipFree(f->d_P));
-    f->d_mean = nm; f->d_P = nP;
-    f->cap_mean = newL.Nq; f->cap_P = (size_t)newL.N * newL.N;
+    swap_state_buffers(f);
     f->lay = newL;
     f->cfg.n_featuresk = nfk; f->cfg.n_featuresk_l = nfkl;
     return SLK_OK;
@@ -665,17 +757,13 @@ static int msckf_window_op(slk_filter *f, int op, int idx)
     HIPCHECK(hipSetDevice(f->cfg.device));
     Lay newL = make_lay(SLK_MSCKF, k_new, 0, 0);
     size_t B = (size_t)f->B;
-    double *nm = nullptr, *nP = nullptr;                      // built out of place, then swapped in
-    HIPCHECK(hipMalloc(&nm, B * newL.Nq * sizeof(double)));
-    HIPCHECK(hipMalloc(&nP, B * (size_t)newL.N * newL.N * sizeof(double)));
+    // push / pop on the stream into the second buffer pair (no hipMalloc, no synchronisation once it has its size)
+    int rc = reserve_alt(f, B * newL.Nq, B * (size_t)newL.N * newL.N);
+    if (rc) return rc;
     hipLaunchKernelGGL(msckf_window_kernel, dim3((newL.N * newL.N + 255) / 256, f->B), dim3(256), 0, f->stream,
-                       f->d_mean, f->d_P, nm, nP, k_old, op, idx);
+                       f->d_mean, f->d_P, f->d_mean_alt, f->d_P_alt, k_old, op, idx);
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipStreamSynchronize(f->stream));
-    HIPCHECK(hipFree(f->d_mean));
-    HIPCHECK(hipFree(f->d_P));
-    f->d_mean = nm; f->d_P = nP;
-    f->cap_mean = newL.Nq; f->cap_P = (size_t)newL.N * newL.N;
+    swap_state_buffers(f);
     f->lay = newL;
     f->cfg.n_clones = k_new;
     return SLK_OK;
@@ -687,21 +775,47 @@ int slk_msckf_drop_clone(slk_filter *f, int index) { return msckf_window_op(f, 2
 int slk_msckf_resize(slk_filter *f, int n_clones)
 {
     if (!f || f->lay.kind != SLK_MSCKF || n_clones < 0) return SLK_E_INVALID;
+    if (12 + 6 * n_clones > 208) { g_err = "state dimension above 208 is not supported by this build"; return SLK_E_UNSUPPORTED; }
     HIPCHECK(hipSetDevice(f->cfg.device));
     Lay newL = make_lay(SLK_MSCKF, n_clones, 0, 0);
     size_t B = (size_t)f->B;
-    HIPCHECK(hipStreamSynchronize(f->stream));
-    double *nm = nullptr, *nP = nullptr;
-    HIPCHECK(hipMalloc(&nm, B * newL.Nq * sizeof(double)));
-    HIPCHECK(hipMalloc(&nP, B * (size_t)newL.N * newL.N * sizeof(double)));
-    HIPCHECK(hipMemsetAsync(nm, 0, B * newL.Nq * sizeof(double), f->stream));
-    HIPCHECK(hipMemsetAsync(nP, 0, B * (size_t)newL.N * newL.N * sizeof(double), f->stream));
-    HIPCHECK(hipStreamSynchronize(f->stream));
-    HIPCHECK(hipFree(f->d_mean));
-    HIPCHECK(hipFree(f->d_P));
-    f->d_mean = nm; f->d_P = nP;
+    const size_t need_mean = B * newL.Nq, need_P = B * (size_t)newL.N * newL.N;
+    if (need_mean > f->cap_mean || need_P > f->cap_P) {            // the zeroed state goes to the second pair, then swap
+        int rc = reserve_alt(f, need_mean, need_P);
+        if (rc) return rc;
+        swap_state_buffers(f);
+    }
+    HIPCHECK(hipMemsetAsync(f->d_mean, 0, need_mean * sizeof(double), f->stream));
+    HIPCHECK(hipMemsetAsync(f->d_P, 0, need_P * sizeof(double), f->stream));
     f->lay = newL;
     f->cfg.n_clones = n_clones;
+    return SLK_OK;
+}
+
+int slk_check_sigma_points(slk_filter *f, double *max_cov_err, double *mean_err, int where)
+{
+    if (!f || f->lay.kind != SLK_MSCKF || !max_cov_err || !mean_err) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    const size_t B = (size_t)f->B, N = (size_t)f->lay.N, Nq = (size_t)f->lay.Nq;
+    int rc = stage_reserve(f, f->st_tmpP, B * N * N);
+    if (rc) return rc;
+    rc = stage_reserve(f, f->st_tmpM, B * Nq + 2 * B);
+    if (rc) return rc;
+    KArgs a;
+    base_args(f, a);
+    a.emit = 3; a.m = 1;
+    a.P_out = f->st_tmpP.p;
+    a.mean_out = f->st_tmpM.p;
+    rc = launch(f, a);
+    if (rc) return rc;
+    double *res = f->st_tmpM.p + B * Nq;                   // [2][B]
+    hipLaunchKernelGGL(check_compare_kernel, dim3(f->B), dim3(256), 0, f->stream, f->lay, (const double *)f->d_mean,
+                       (const double *)f->d_P, (const double *)a.mean_out, (const double *)a.P_out, f->B, res);
+    HIPCHECK(hipGetLastError());
+    const hipMemcpyKind kind = where == SLK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    HIPCHECK(hipMemcpyAsync(max_cov_err, res, B * sizeof(double), kind, f->stream));
+    HIPCHECK(hipMemcpyAsync(mean_err, res + B, B * sizeof(double), kind, f->stream));
+    if (where == SLK_HOST) HIPCHECK(hipStreamSynchronize(f->stream));
     return SLK_OK;
 }
 

@@ -36,7 +36,8 @@ struct KArgs {
     int do_update, mm; const double *mp; int mp_stride; const double *z; int m;
     const double *R; int r_stride; int gate; const double *Zext;
     // tier B sigma-point emission: 1 = predict sigma points, 2 = update sigma points
-    int emit; double *Xout;
+    int emit; double *Xout;     // 3 = checkSigmaPoints: re-draw, mean and covariance into mean_out / P_out
+    double *mean_out, *P_out;   // null = in place
     int rebuild_prec;     // covariance rebuild arithmetic: 0 = fp64 (parity path), 1 = fp32 MFMA, 2 = bf16 inputs / fp32 accumulate
     double *wsL, *wsDR;   // global workspaces of the large-state path (N > 80): packed factor, rotation deviations
     const unsigned long long *rtab;   // Msckf: descriptors of the rotation items (layout only, built by the host)
@@ -828,6 +829,28 @@ __host__ __device__ __forceinline__ int measure_features(int mm, int m)
     return mm == SLK_MM_FEATURE_PROJ ? m / 2 : (mm == SLK_MM_POSE_POSITION ? 1 : m / 3);
 }
 
+// Pose indices of the registered measurement models are caller data: 0 .. k (Msckf: current state, clones) or 0 .. 2
+// (Usckf: statek, statek_l, statek_i).  Anything else (negative, NaN, too large) would index mu / the factor out of
+// range: the update is skipped and SLK_ST_BAD_INDEX reported.  Uniform over the workgroup (every thread reads the
+// same few parameters).
+__device__ __forceinline__ bool pose_params_ok(const KArgs &a, const Lay &L, const double *mp)
+{
+    const double maxc = (L.kind == SLK_MSCKF) ? (double)L.k : 2.0;
+    if (a.mm == SLK_MM_FEATURE_PROJ) {
+        bool ok = true;
+        for (int f = 0; f < a.m / 2; ++f) {
+            const double c = mp[4 * f + 3];
+            ok = ok && (c >= 0.0) && (c <= maxc);      // false for NaN
+        }
+        return ok;
+    }
+    if (a.mm == SLK_MM_POSE_POSITION) {
+        const double c = mp[0];
+        return (c >= 0.0) && (c <= maxc);
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------ measurement moments
 // Z = h(X) over the implicit sigma points of (mu, L), mean_z, innovation, S = 1/2 dZ dZ^T + R and
 // covXZ = 1/2 sum (X_i [-] mu)(Z_i - mean_z)^T  (Msckf.hpp:231-239, Usckf.hpp:277-283).
@@ -1275,6 +1298,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
     int *roff = ish + 48;                                     // nso3 + 1 prefix offsets of the rotation items
     double *gmean = a.mean + (size_t)bidx * Nq;
     double *gP = a.P + (size_t)bidx * N * N;
+    double *omean = a.mean_out ? a.mean_out + (size_t)bidx * Nq : gmean;     // where applyDelta's results go
+    double *oP = a.P_out ? a.P_out + (size_t)bidx * N * N : gP;
     int status = 0;
     if (a.do_update && tid == 0) a.outliers[bidx] = 0u;
     SLK_STAMP(0);
@@ -1323,7 +1348,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
     };
 
     SLK_STAMP(2);
-    if (a.do_update || a.emit == 2) {
+    if (a.do_update || a.emit >= 2) {
         // ---- sigma points of the full state: Msckf.hpp:228-229 -> :400-431
         int fail;
         constexpr bool WCHOL = NT >= 3 && NT <= 4 && NW >= NT;   // one tile row per wave
@@ -1346,8 +1371,15 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
             fail = chol_packed<NTHREADS, SDN>(Lp, N, colbuf, tid, Pin);
         }
         SLK_STAMP(3);
+        bool redraw = false;
         if (fail >= 0) {
             status |= SLK_ST_LLT_FAIL;
+        } else if (a.emit == 3) {
+            // checkSigmaPoints (Msckf.hpp:819-839): re-draw (mu, 0, Pk), manifold mean and covariance go to the
+            // caller's scratch (a.mean_out / a.P_out), the filter itself is left as it is
+            for (int t = tid; t < N; t += NTHREADS) delta[t] = 0.0;
+            __syncthreads();
+            redraw = true;
         } else if (a.emit == 2) {
             double *X = a.Xout + (size_t)bidx * S * Nq;
             for (int e = tid; e < S * N; e += NTHREADS) {
@@ -1361,6 +1393,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 double *o = X + (size_t)i * Nq + so3_soff(L, b);
                 o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
             }
+        } else if (!pose_params_ok(a, L, a.mp ? a.mp + (size_t)bidx * a.mp_stride : nullptr)) {
+            status |= SLK_ST_BAD_INDEX;                       // pose index of a registered model out of range: update skipped
         } else {
             // ---- pool carve for the measurement part
             double *Z = pool;                                   // [S][m]
@@ -1586,319 +1620,322 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                     if (fail >= 0) {
                         status |= SLK_ST_LLT_FAIL;
                     } else {
-                        // ---- re-drawn sigma points, manifold mean (:664 -> :499-525), covariance (:665)
-                        const int W = cv.W;
-                        double *DR = BIG ? a.wsDR + (size_t)bidx * 3 * W : pool;   // rotation deviations, 3 per stored item
-                        double *Dp = BIG ? pool : pool + round_up(3 * W, 2);       // [2][KP][LDD] panels
-                        // reference = X[0] = mu + delta (:501)
-                        for (int t = tid; t < N; t += NTHREADS) {
-                            int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
-                            if (s >= 0) ref[s] = mu[s] + delta[t];
-                        }
-                        for (int b = tid; b < nso3; b += NTHREADS)
-                            stq(ref + so3_soff(L, b), sigma_quat(L, mu, Lp, delta, b, sig_of(0)));
-                        __syncthreads();
-                        int it = 0;
-                        double norm = 0.0;
-                        bool final_pass = false;
-                        for (;;) {                                        // :507-516, then one pass against the final mean (:584)
-                            // rotation blocks of X_i [-] ref, only the sigma points whose block differs from X_0's
-                            for (int w = tid; w < W; w += NTHREADS) {
-                                double dx, dy, dz;
-                                rot_deviation_desc(a.rtab[w], mu, ref, Lp, delta, dx, dy, dz);
-                                DR[3 * w] = dx; DR[3 * w + 1] = dy; DR[3 * w + 2] = dz;
-                            }
-                            __syncthreads();
-                            if (final_pass) break;
-                            // mean_delta = sum_i (X_i [-] ref) / S.  Vector rows: the +-L_j terms of the pairs
-                            // cancel, every sigma point contributes (mu + delta) - ref.  Rotation rows: 8 lanes
-                            // per row over the stored deviations, the other S - cnt points equal X_0's.
-                            for (int t = tid; t < N; t += NTHREADS) {
-                                int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
-                                if (s >= 0) md[t] = (mu[s] + delta[t]) - ref[s];
-                            }
-                            for (int e = tid / 8; e < 3 * nso3; e += NTHREADS / 8) {
-                                const int blk = e / 3, comp = e - 3 * blk, sub = tid & 7;
-                                const int r0 = msckf_roff(blk), cnt = msckf_roff(blk + 1) - r0;
-                                const double *row = DR + 3 * r0 + comp;
-                                double sum = group_sum<8>(sub, cnt, [&](int i) { return row[3 * i]; });
-                                sum += (double)(S - cnt) * row[0];
-                                if (sub == 0) md[msckf_toff(blk) + comp] = sum / (double)S;
-                            }
-                            __syncthreads();
-                            double n2 = group_sum<64>(lane, N, [&](int t) { return md[t] * md[t]; });
-                            norm = sqrt(n2);
-                            for (int t = tid; t < N; t += NTHREADS) {       // reference += mean_delta
-                                int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
-                                if (s >= 0) ref[s] = ref[s] + md[t];
-                            }
-                            for (int b = tid; b < nso3; b += NTHREADS) {
-                                int to = msckf_toff(b), so = msckf_soff(b);
-                                stq(ref + so, qmul(ldq(ref + so), so3_exp(md[to], md[to + 1], md[to + 2])));
-                            }
-                            __syncthreads();
-                            if (!(norm > 1e-6 && ++it < 10000)) final_pass = true;
-                        }
-                        if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
-                        SLK_STAMP(12);
-                        SLK_NOTE(20, it + 1);
-                        // mean written out now: `ref` is final
-                        for (int e = tid; e < Nq; e += NTHREADS) gmean[e] = ref[e];
-                        SLK_STAMP(13);
-                        // ---- P+ = 1/2 D D^T on the fp64 matrix cores (:665 -> :574-589), D generated panel by
-                        // panel: vector rows straight from the factor, rotation rows from DR
-                        constexpr int TN = 16 * NT;
-                        constexpr int RPT = (TN + 63) / 64;                 // rows of D handled per lane
-                        constexpr int TPW = TilePlan<NT, NW>::TPW;
-                        int rkind[RPT], roffs[RPT], rcnt[RPT];
-                        double rm[RPT], rd[RPT], rr[RPT];
-#pragma unroll
-                        for (int q = 0; q < RPT; ++q) {
-                            int t = lane + 64 * q, blk = 0, comp = 0;
-                            rkind[q] = 0; roffs[q] = 0; rcnt[q] = 0; rm[q] = 0.0; rd[q] = 0.0; rr[q] = 0.0;
-                            if (t < N) {
-                                int s = t2s(L, t, blk, comp);
-                                if (s >= 0) { rkind[q] = 1; rm[q] = mu[s]; rd[q] = delta[t]; rr[q] = ref[s]; }
-                                else { rkind[q] = 2; roffs[q] = 3 * roff[blk] + comp; rcnt[q] = roff[blk + 1] - roff[blk]; }
-                            } else if (t >= TN) rkind[q] = 3;
-                        }
-                        auto gen_panel = [&](int p0, double *Dq) __attribute__((always_inline)) {
-                            for (int kk = wave; kk < KP; kk += NW) {
-                                const int i = p0 + kk;
-                                const int j = (i - 1) >> 1;
-                                const double sgn = (i & 1) ? 1.0 : -1.0;
-                                const int jb = ((j * (2 * N - j + 1)) >> 1) - j;          // pk(N, t, j) = jb + t
-                                // all loads of this column first (branch-free: clamped address, select later)
-                                double lv[RPT];
-#pragma unroll
-                                for (int q = 0; q < RPT; ++q) {
-                                    const int t = lane + 64 * q;
-                                    const bool vec = rkind[q] == 1 && i > 0 && i < S && j <= t;
-                                    const bool rot = rkind[q] == 2 && i < S;
-                                    const double *src = rot ? DR + (roffs[q] + 3 * (i < rcnt[q] ? i : 0)) : Lp + (vec ? jb + t : 0);
-                                    lv[q] = *src;
-                                }
-#pragma unroll
-                                for (int q = 0; q < RPT; ++q) {
-                                    const int t = lane + 64 * q;
-                                    double v = 0.0;
-                                    if (i < S) {
-                                        if (rkind[q] == 1) {
-                                            const double l = (i > 0 && j <= t) ? sgn * lv[q] : 0.0;
-                                            v = (rm[q] + (rd[q] + l)) - rr[q];
-                                        } else if (rkind[q] == 2) {
-                                            v = lv[q];
-                                        }
-                                    }
-                                    if (rkind[q] != 3) Dq[kk * LDD + t] = v;
-                                }
-                            }
-                        };
-                        bool rebuilt = false;
-                        if constexpr (NT <= 4) {
-                            if (a.rebuild_prec == 0) {
-                                // ---- K-split rebuild: every wave owns ALL lower tiles for its share of the sigma
-                                // points (k-steps dealt round-robin), builds its A/B fragments straight from the
-                                // packed factor / the rotation deviations -- no panel staging, no barrier, no
-                                // fragment computed twice -- and the partial tiles are summed through LDS, which
-                                // also lets both triangles go out as contiguous 128-byte rows.
-                                constexpr int NTL = CholM<NT>::NTL;
-                                // four waves = 2 halves of the sigma points x 2 halves of the tile list: 5 accumulator
-                                // tiles per wave instead of 10 (registers), two partial sums per tile instead of four
-                                constexpr int TSPLIT = (NW == 4) ? 2 : 1;          // tile groups
-                                constexpr int KSPLIT = NW / TSPLIT;                // sigma-point groups
-                                constexpr int HALF = (NTL + TSPLIT - 1) / TSPLIT;  // tiles per group
-                                const int th = (TSPLIT == 2) ? (wave >> 1) : 0, kh = (TSPLIT == 2) ? (wave & 1) : wave;
-                                d4 acc[HALF];
-#pragma unroll
-                                for (int q = 0; q < HALF; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-                                const int c16 = lane & 15, g4 = lane >> 4;
-                                // Row t = 16 I + c16 of D, per lane and tile row, in ONE branch-free form
-                                //   D(t, i) = (qm + (qd + f * smem[bas + (c ? y : 0)])) - qr
-                                // vector row : bas = factor, c = j < t + 1, y = pk(N, t, j), f = c ? sgn : 0
-                                // rotation   : bas = its deviations, c = i < count, y = 3 i, f = 1, qm = qd = qr = 0
-                                // padding    : a vector row with threshold 0 and zero constants
-                                bool isv[NT];
-                                int bas[NT], thr[NT];
-                                double qm[NT], qd[NT], qr[NT];
-                                const int LpOff = (int)(Lp - smem), DROff = (int)(DR - smem);
-#pragma unroll
-                                for (int I = 0; I < NT; ++I) {
-                                    int t = 16 * I + c16, blk = 0, comp = 0;
-                                    isv[I] = true; bas[I] = LpOff; thr[I] = 0; qm[I] = 0.0; qd[I] = 0.0; qr[I] = 0.0;
-                                    if (t < N) {
-                                        int s = t2s(L, t, blk, comp);
-                                        if (s >= 0) { thr[I] = t + 1; qm[I] = mu[s]; qd[I] = delta[t]; qr[I] = ref[s]; }
-                                        else {
-                                            isv[I] = false;
-                                            bas[I] = DROff + 3 * msckf_roff(blk) + comp;
-                                            thr[I] = msckf_roff(blk + 1) - msckf_roff(blk);
-                                        }
-                                    }
-                                }
-                                const int nks = (S + 3) >> 2;
-                                for (int ks = kh; ks < nks; ks += KSPLIT) {
-                                    const int i = 4 * ks + g4;
-                                    const bool valid = i < S;
-                                    const int j = (i > 0) ? ((i - 1) >> 1) : 0;
-                                    const double sgn = (i == 0) ? 0.0 : ((i & 1) ? 1.0 : -1.0);
-                                    const int jbc = ((j * (2 * N - j + 1)) >> 1) - j + c16;   // pk(N, t, j) = jbc + 16 I
-                                    const int i3 = 3 * i;
-                                    double frag[NT];
-                                    constexpr int ROWS_A = TileMap<NT>::row(HALF - 1) + 1;   // tile rows the first tile group touches
-#pragma unroll
-                                    for (int I = 0; I < NT; ++I) {
-                                        if (TSPLIT == 2 && I >= ROWS_A && th == 0) { frag[I] = 0.0; continue; }
-                                        const bool c = (isv[I] ? j : i) < thr[I];
-                                        const int y = isv[I] ? jbc + 16 * I : i3;
-                                        const double l = smem[bas[I] + (c ? y : 0)];
-                                        const double f = isv[I] ? (c ? sgn : 0.0) : 1.0;
-                                        const double v = (qm[I] + (qd[I] + f * l)) - qr[I];
-                                        frag[I] = valid ? v : 0.0;
-                                    }
-#pragma unroll
-                                    for (int I = 0; I < NT; ++I)
-#pragma unroll
-                                        for (int J = 0; J <= I; ++J)
-                                            if (tile_idx(I, J) / HALF == th)
-                                                acc[tile_idx(I, J) % HALF] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-                                                    frag[I], frag[J], acc[tile_idx(I, J) % HALF], 0, 0, 0);
-                                }
-                                __syncthreads();                     // factor, deviations and vectors are dead from here
-                                SLK_STAMP(14);
-                                constexpr int TS = 16 * 17;          // padded 16x16 tile, [col][row]
-                                int TR = cv.total / (KSPLIT * TS);
-                                if (TR > NTL) TR = NTL;
-                                double *red = smem;
-                                const int ea = tid & 15, eb = (tid >> 4) & 15;
-                                for (int T0 = 0; T0 < NTL; T0 += TR) {
-#pragma unroll
-                                    for (int T = 0; T < NTL; ++T)
-                                        if (T / HALF == th && T >= T0 && T < T0 + TR) {
-                                            double *dst = red + (kh * TR + (T - T0)) * TS + c16 * 17 + g4;
-#pragma unroll
-                                            for (int q = 0; q < 4; ++q) dst[4 * q] = acc[T % HALF][q];
-                                        }
-                                    __syncthreads();
-                                    const int ntl = (NTL - T0 < TR) ? NTL - T0 : TR;
-                                    // 256 threads per tile (the 64-thread kernels take four strides); tile index uniform
-                                    for (int Tl = 0; Tl < ntl; ++Tl) {
-                                        const int T = T0 + Tl;
-                                        const int I = (T >= 1) + (T >= 3) + (T >= 6), J = T - I * (I + 1) / 2;
-                                        const double *src = red + Tl * TS;
-                                        for (int e2 = eb; e2 < 16; e2 += NTHREADS / 16) {
-                                            {   // lower triangle: consecutive lanes = consecutive rows of one column
-                                                double sum = 0.0;
-#pragma unroll
-                                                for (int w = 0; w < KSPLIT; ++w) sum += src[w * TR * TS + e2 * 17 + ea];
-                                                const int row = 16 * I + ea, col = 16 * J + e2;
-                                                if (row < N && col < N) gP[row + (size_t)col * N] = 0.5 * sum;
-                                            }
-                                            if (I != J) {   // mirrored copy, again contiguous in the fast index
-                                                double sum = 0.0;
-#pragma unroll
-                                                for (int w = 0; w < KSPLIT; ++w) sum += src[w * TR * TS + ea * 17 + e2];
-                                                const int row = 16 * I + e2, col = 16 * J + ea;
-                                                if (row < N && col < N) gP[col + (size_t)row * N] = 0.5 * sum;
-                                            }
-                                        }
-                                    }
-                                    __syncthreads();
-                                }
-                                rebuilt = true;
-                            }
-                        }
-                        if (rebuilt) {
-                        } else if (a.rebuild_prec == 0) {
-                        for (int pass = 0; pass < TilePlan<NT, NW>::PASSES; ++pass) {
-                            d4 acc[TPW];
-#pragma unroll
-                            for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-                            gen_panel(0, Dp);
-                            __syncthreads();
-                            int pb = 0;
-                            for (int p0 = 0; p0 < S; p0 += KP, pb ^= 1) {
-                                const double *Dc = Dp + pb * KP * LDD;
-#pragma unroll
-                                for (int ks = 0; ks < KP / 4; ++ks) {
-                                    double frag[NT];
-#pragma unroll
-                                    for (int I = 0; I < NT; ++I) frag[I] = Dc[(4 * ks + (lane >> 4)) * LDD + 16 * I + (lane & 15)];
-                                    MfmaTiles<NT, NW, 0>::run(frag, acc, wave, pass);
-                                }
-                                if (p0 + KP < S) gen_panel(p0 + KP, Dp + (pb ^ 1) * KP * LDD);
-                                __syncthreads();
-                            }
-                            SLK_STAMP(14);
-                            MfmaTiles<NT, NW, 0>::store(gP, N, acc, wave, lane, pass);
-                        }
-                        } else if (a.rebuild_prec == 1) {
-                            // ---- precision sweep: fp32 operands and accumulation
-                            for (int pass = 0; pass < TilePlan<NT, NW>::PASSES; ++pass) {
-                                f4 acc[TPW];
-#pragma unroll
-                                for (int q = 0; q < TPW; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
-                                gen_panel(0, Dp);
-                                __syncthreads();
-                                int pb = 0;
-                                for (int p0 = 0; p0 < S; p0 += KP, pb ^= 1) {
-                                    const double *Dc = Dp + pb * KP * LDD;
-#pragma unroll
-                                    for (int ks = 0; ks < KP / 4; ++ks) {
-                                        float frag[NT];
-#pragma unroll
-                                        for (int I = 0; I < NT; ++I)
-                                            frag[I] = (float)Dc[(4 * ks + (lane >> 4)) * LDD + 16 * I + (lane & 15)];
-                                        MfmaTiles32<NT, NW, 0>::run(frag, acc, wave, pass);
-                                    }
-                                    if (p0 + KP < S) gen_panel(p0 + KP, Dp + (pb ^ 1) * KP * LDD);
-                                    __syncthreads();
-                                }
-                                MfmaTiles32<NT, NW, 0>::store(gP, N, acc, wave, lane, pass);
-                            }
-                        } else {
-                            // ---- precision sweep: bf16 operands, fp32 accumulation, 32 sigma points per MFMA.
-                            // Panel = bf16 [16*NT rows][32 sigma points] (64-byte rows), single-buffered.
-                            __bf16 *Db = reinterpret_cast<__bf16 *>(Dp);
-                            for (int pass = 0; pass < TilePlan<NT, NW>::PASSES; ++pass) {
-                                f4 acc[TPW];
-#pragma unroll
-                                for (int q = 0; q < TPW; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
-                                for (int p0 = 0; p0 < S; p0 += 32) {
-                                    for (int kk = wave; kk < 32; kk += NW) {
-                                        const int i = p0 + kk;
-                                        const int j = (i - 1) >> 1;
-                                        const double sgn = (i & 1) ? 1.0 : -1.0;
-#pragma unroll
-                                        for (int q = 0; q < RPT; ++q) {
-                                            const int t = lane + 64 * q;
-                                            double v = 0.0;
-                                            if (i < S) {
-                                                if (rkind[q] == 1) {
-                                                    double l = (i > 0 && j <= t) ? sgn * Lp[pk(N, t, j)] : 0.0;
-                                                    v = (rm[q] + (rd[q] + l)) - rr[q];
-                                                } else if (rkind[q] == 2) {
-                                                    v = DR[roffs[q] + 3 * (i < rcnt[q] ? i : 0)];
-                                                }
-                                            }
-                                            if (rkind[q] != 3) Db[t * 32 + kk] = (__bf16)(float)v;
-                                        }
-                                    }
-                                    __syncthreads();
-                                    b8 frag[NT];
-#pragma unroll
-                                    for (int I = 0; I < NT; ++I)
-                                        frag[I] = *reinterpret_cast<const b8 *>(Db + (16 * I + (lane & 15)) * 32 + 8 * (lane >> 4));
-                                    MfmaTiles32<NT, NW, 0>::run_bf16(frag, acc, wave, pass);
-                                    __syncthreads();
-                                }
-                                MfmaTiles32<NT, NW, 0>::store(gP, N, acc, wave, lane, pass);
-                            }
-                        }
-                        SLK_STAMP(15);
+                        redraw = true;
                     }
                 }
             }
+        }
+        if (redraw) {
+            // ---- re-drawn sigma points, manifold mean (:664 -> :499-525), covariance (:665)
+            const int W = cv.W;
+            double *DR = BIG ? a.wsDR + (size_t)bidx * 3 * W : pool;   // rotation deviations, 3 per stored item
+            double *Dp = BIG ? pool : pool + round_up(3 * W, 2);       // [2][KP][LDD] panels
+            // reference = X[0] = mu + delta (:501)
+            for (int t = tid; t < N; t += NTHREADS) {
+                int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
+                if (s >= 0) ref[s] = mu[s] + delta[t];
+            }
+            for (int b = tid; b < nso3; b += NTHREADS)
+                stq(ref + so3_soff(L, b), sigma_quat(L, mu, Lp, delta, b, sig_of(0)));
+            __syncthreads();
+            int it = 0;
+            double norm = 0.0;
+            bool final_pass = false;
+            for (;;) {                                        // :507-516, then one pass against the final mean (:584)
+                // rotation blocks of X_i [-] ref, only the sigma points whose block differs from X_0's
+                for (int w = tid; w < W; w += NTHREADS) {
+                    double dx, dy, dz;
+                    rot_deviation_desc(a.rtab[w], mu, ref, Lp, delta, dx, dy, dz);
+                    DR[3 * w] = dx; DR[3 * w + 1] = dy; DR[3 * w + 2] = dz;
+                }
+                __syncthreads();
+                if (final_pass) break;
+                // mean_delta = sum_i (X_i [-] ref) / S.  Vector rows: the +-L_j terms of the pairs
+                // cancel, every sigma point contributes (mu + delta) - ref.  Rotation rows: 8 lanes
+                // per row over the stored deviations, the other S - cnt points equal X_0's.
+                for (int t = tid; t < N; t += NTHREADS) {
+                    int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
+                    if (s >= 0) md[t] = (mu[s] + delta[t]) - ref[s];
+                }
+                for (int e = tid / 8; e < 3 * nso3; e += NTHREADS / 8) {
+                    const int blk = e / 3, comp = e - 3 * blk, sub = tid & 7;
+                    const int r0 = msckf_roff(blk), cnt = msckf_roff(blk + 1) - r0;
+                    const double *row = DR + 3 * r0 + comp;
+                    double sum = group_sum<8>(sub, cnt, [&](int i) { return row[3 * i]; });
+                    sum += (double)(S - cnt) * row[0];
+                    if (sub == 0) md[msckf_toff(blk) + comp] = sum / (double)S;
+                }
+                __syncthreads();
+                double n2 = group_sum<64>(lane, N, [&](int t) { return md[t] * md[t]; });
+                norm = sqrt(n2);
+                for (int t = tid; t < N; t += NTHREADS) {       // reference += mean_delta
+                    int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
+                    if (s >= 0) ref[s] = ref[s] + md[t];
+                }
+                for (int b = tid; b < nso3; b += NTHREADS) {
+                    int to = msckf_toff(b), so = msckf_soff(b);
+                    stq(ref + so, qmul(ldq(ref + so), so3_exp(md[to], md[to + 1], md[to + 2])));
+                }
+                __syncthreads();
+                if (!(norm > 1e-6 && ++it < 10000)) final_pass = true;
+            }
+            if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
+            SLK_STAMP(12);
+            SLK_NOTE(20, it + 1);
+            // mean written out now: `ref` is final
+            for (int e = tid; e < Nq; e += NTHREADS) omean[e] = ref[e];
+            SLK_STAMP(13);
+            // ---- P+ = 1/2 D D^T on the fp64 matrix cores (:665 -> :574-589), D generated panel by
+            // panel: vector rows straight from the factor, rotation rows from DR
+            constexpr int TN = 16 * NT;
+            constexpr int RPT = (TN + 63) / 64;                 // rows of D handled per lane
+            constexpr int TPW = TilePlan<NT, NW>::TPW;
+            int rkind[RPT], roffs[RPT], rcnt[RPT];
+            double rm[RPT], rd[RPT], rr[RPT];
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                int t = lane + 64 * q, blk = 0, comp = 0;
+                rkind[q] = 0; roffs[q] = 0; rcnt[q] = 0; rm[q] = 0.0; rd[q] = 0.0; rr[q] = 0.0;
+                if (t < N) {
+                    int s = t2s(L, t, blk, comp);
+                    if (s >= 0) { rkind[q] = 1; rm[q] = mu[s]; rd[q] = delta[t]; rr[q] = ref[s]; }
+                    else { rkind[q] = 2; roffs[q] = 3 * roff[blk] + comp; rcnt[q] = roff[blk + 1] - roff[blk]; }
+                } else if (t >= TN) rkind[q] = 3;
+            }
+            auto gen_panel = [&](int p0, double *Dq) __attribute__((always_inline)) {
+                for (int kk = wave; kk < KP; kk += NW) {
+                    const int i = p0 + kk;
+                    const int j = (i - 1) >> 1;
+                    const double sgn = (i & 1) ? 1.0 : -1.0;
+                    const int jb = ((j * (2 * N - j + 1)) >> 1) - j;          // pk(N, t, j) = jb + t
+                    // all loads of this column first (branch-free: clamped address, select later)
+                    double lv[RPT];
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q) {
+                        const int t = lane + 64 * q;
+                        const bool vec = rkind[q] == 1 && i > 0 && i < S && j <= t;
+                        const bool rot = rkind[q] == 2 && i < S;
+                        const double *src = rot ? DR + (roffs[q] + 3 * (i < rcnt[q] ? i : 0)) : Lp + (vec ? jb + t : 0);
+                        lv[q] = *src;
+                    }
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q) {
+                        const int t = lane + 64 * q;
+                        double v = 0.0;
+                        if (i < S) {
+                            if (rkind[q] == 1) {
+                                const double l = (i > 0 && j <= t) ? sgn * lv[q] : 0.0;
+                                v = (rm[q] + (rd[q] + l)) - rr[q];
+                            } else if (rkind[q] == 2) {
+                                v = lv[q];
+                            }
+                        }
+                        if (rkind[q] != 3) Dq[kk * LDD + t] = v;
+                    }
+                }
+            };
+            bool rebuilt = false;
+            if constexpr (NT <= 4) {
+                if (a.rebuild_prec == 0) {
+                    // ---- K-split rebuild: every wave owns ALL lower tiles for its share of the sigma
+                    // points (k-steps dealt round-robin), builds its A/B fragments straight from the
+                    // packed factor / the rotation deviations -- no panel staging, no barrier, no
+                    // fragment computed twice -- and the partial tiles are summed through LDS, which
+                    // also lets both triangles go out as contiguous 128-byte rows.
+                    constexpr int NTL = CholM<NT>::NTL;
+                    // four waves = 2 halves of the sigma points x 2 halves of the tile list: 5 accumulator
+                    // tiles per wave instead of 10 (registers), two partial sums per tile instead of four
+                    constexpr int TSPLIT = (NW == 4) ? 2 : 1;          // tile groups
+                    constexpr int KSPLIT = NW / TSPLIT;                // sigma-point groups
+                    constexpr int HALF = (NTL + TSPLIT - 1) / TSPLIT;  // tiles per group
+                    const int th = (TSPLIT == 2) ? (wave >> 1) : 0, kh = (TSPLIT == 2) ? (wave & 1) : wave;
+                    d4 acc[HALF];
+#pragma unroll
+                    for (int q = 0; q < HALF; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+                    const int c16 = lane & 15, g4 = lane >> 4;
+                    // Row t = 16 I + c16 of D, per lane and tile row, in ONE branch-free form
+                    //   D(t, i) = (qm + (qd + f * smem[bas + (c ? y : 0)])) - qr
+                    // vector row : bas = factor, c = j < t + 1, y = pk(N, t, j), f = c ? sgn : 0
+                    // rotation   : bas = its deviations, c = i < count, y = 3 i, f = 1, qm = qd = qr = 0
+                    // padding    : a vector row with threshold 0 and zero constants
+                    bool isv[NT];
+                    int bas[NT], thr[NT];
+                    double qm[NT], qd[NT], qr[NT];
+                    const int LpOff = (int)(Lp - smem), DROff = (int)(DR - smem);
+#pragma unroll
+                    for (int I = 0; I < NT; ++I) {
+                        int t = 16 * I + c16, blk = 0, comp = 0;
+                        isv[I] = true; bas[I] = LpOff; thr[I] = 0; qm[I] = 0.0; qd[I] = 0.0; qr[I] = 0.0;
+                        if (t < N) {
+                            int s = t2s(L, t, blk, comp);
+                            if (s >= 0) { thr[I] = t + 1; qm[I] = mu[s]; qd[I] = delta[t]; qr[I] = ref[s]; }
+                            else {
+                                isv[I] = false;
+                                bas[I] = DROff + 3 * msckf_roff(blk) + comp;
+                                thr[I] = msckf_roff(blk + 1) - msckf_roff(blk);
+                            }
+                        }
+                    }
+                    const int nks = (S + 3) >> 2;
+                    for (int ks = kh; ks < nks; ks += KSPLIT) {
+                        const int i = 4 * ks + g4;
+                        const bool valid = i < S;
+                        const int j = (i > 0) ? ((i - 1) >> 1) : 0;
+                        const double sgn = (i == 0) ? 0.0 : ((i & 1) ? 1.0 : -1.0);
+                        const int jbc = ((j * (2 * N - j + 1)) >> 1) - j + c16;   // pk(N, t, j) = jbc + 16 I
+                        const int i3 = 3 * i;
+                        double frag[NT];
+                        constexpr int ROWS_A = TileMap<NT>::row(HALF - 1) + 1;   // tile rows the first tile group touches
+#pragma unroll
+                        for (int I = 0; I < NT; ++I) {
+                            if (TSPLIT == 2 && I >= ROWS_A && th == 0) { frag[I] = 0.0; continue; }
+                            const bool c = (isv[I] ? j : i) < thr[I];
+                            const int y = isv[I] ? jbc + 16 * I : i3;
+                            const double l = smem[bas[I] + (c ? y : 0)];
+                            const double f = isv[I] ? (c ? sgn : 0.0) : 1.0;
+                            const double v = (qm[I] + (qd[I] + f * l)) - qr[I];
+                            frag[I] = valid ? v : 0.0;
+                        }
+#pragma unroll
+                        for (int I = 0; I < NT; ++I)
+#pragma unroll
+                            for (int J = 0; J <= I; ++J)
+                                if (tile_idx(I, J) / HALF == th)
+                                    acc[tile_idx(I, J) % HALF] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                                        frag[I], frag[J], acc[tile_idx(I, J) % HALF], 0, 0, 0);
+                    }
+                    __syncthreads();                     // factor, deviations and vectors are dead from here
+                    SLK_STAMP(14);
+                    constexpr int TS = 16 * 17;          // padded 16x16 tile, [col][row]
+                    int TR = cv.total / (KSPLIT * TS);
+                    if (TR > NTL) TR = NTL;
+                    double *red = smem;
+                    const int ea = tid & 15, eb = (tid >> 4) & 15;
+                    for (int T0 = 0; T0 < NTL; T0 += TR) {
+#pragma unroll
+                        for (int T = 0; T < NTL; ++T)
+                            if (T / HALF == th && T >= T0 && T < T0 + TR) {
+                                double *dst = red + (kh * TR + (T - T0)) * TS + c16 * 17 + g4;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) dst[4 * q] = acc[T % HALF][q];
+                            }
+                        __syncthreads();
+                        const int ntl = (NTL - T0 < TR) ? NTL - T0 : TR;
+                        // 256 threads per tile (the 64-thread kernels take four strides); tile index uniform
+                        for (int Tl = 0; Tl < ntl; ++Tl) {
+                            const int T = T0 + Tl;
+                            const int I = (T >= 1) + (T >= 3) + (T >= 6), J = T - I * (I + 1) / 2;
+                            const double *src = red + Tl * TS;
+                            for (int e2 = eb; e2 < 16; e2 += NTHREADS / 16) {
+                                {   // lower triangle: consecutive lanes = consecutive rows of one column
+                                    double sum = 0.0;
+#pragma unroll
+                                    for (int w = 0; w < KSPLIT; ++w) sum += src[w * TR * TS + e2 * 17 + ea];
+                                    const int row = 16 * I + ea, col = 16 * J + e2;
+                                    if (row < N && col < N) oP[row + (size_t)col * N] = 0.5 * sum;
+                                }
+                                if (I != J) {   // mirrored copy, again contiguous in the fast index
+                                    double sum = 0.0;
+#pragma unroll
+                                    for (int w = 0; w < KSPLIT; ++w) sum += src[w * TR * TS + ea * 17 + e2];
+                                    const int row = 16 * I + e2, col = 16 * J + ea;
+                                    if (row < N && col < N) oP[col + (size_t)row * N] = 0.5 * sum;
+                                }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    rebuilt = true;
+                }
+            }
+            if (rebuilt) {
+            } else if (a.rebuild_prec == 0) {
+            for (int pass = 0; pass < TilePlan<NT, NW>::PASSES; ++pass) {
+                d4 acc[TPW];
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+                gen_panel(0, Dp);
+                __syncthreads();
+                int pb = 0;
+                for (int p0 = 0; p0 < S; p0 += KP, pb ^= 1) {
+                    const double *Dc = Dp + pb * KP * LDD;
+#pragma unroll
+                    for (int ks = 0; ks < KP / 4; ++ks) {
+                        double frag[NT];
+#pragma unroll
+                        for (int I = 0; I < NT; ++I) frag[I] = Dc[(4 * ks + (lane >> 4)) * LDD + 16 * I + (lane & 15)];
+                        MfmaTiles<NT, NW, 0>::run(frag, acc, wave, pass);
+                    }
+                    if (p0 + KP < S) gen_panel(p0 + KP, Dp + (pb ^ 1) * KP * LDD);
+                    __syncthreads();
+                }
+                SLK_STAMP(14);
+                MfmaTiles<NT, NW, 0>::store(oP, N, acc, wave, lane, pass);
+            }
+            } else if (a.rebuild_prec == 1) {
+                // ---- precision sweep: fp32 operands and accumulation
+                for (int pass = 0; pass < TilePlan<NT, NW>::PASSES; ++pass) {
+                    f4 acc[TPW];
+#pragma unroll
+                    for (int q = 0; q < TPW; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
+                    gen_panel(0, Dp);
+                    __syncthreads();
+                    int pb = 0;
+                    for (int p0 = 0; p0 < S; p0 += KP, pb ^= 1) {
+                        const double *Dc = Dp + pb * KP * LDD;
+#pragma unroll
+                        for (int ks = 0; ks < KP / 4; ++ks) {
+                            float frag[NT];
+#pragma unroll
+                            for (int I = 0; I < NT; ++I)
+                                frag[I] = (float)Dc[(4 * ks + (lane >> 4)) * LDD + 16 * I + (lane & 15)];
+                            MfmaTiles32<NT, NW, 0>::run(frag, acc, wave, pass);
+                        }
+                        if (p0 + KP < S) gen_panel(p0 + KP, Dp + (pb ^ 1) * KP * LDD);
+                        __syncthreads();
+                    }
+                    MfmaTiles32<NT, NW, 0>::store(oP, N, acc, wave, lane, pass);
+                }
+            } else {
+                // ---- precision sweep: bf16 operands, fp32 accumulation, 32 sigma points per MFMA.
+                // Panel = bf16 [16*NT rows][32 sigma points] (64-byte rows), single-buffered.
+                __bf16 *Db = reinterpret_cast<__bf16 *>(Dp);
+                for (int pass = 0; pass < TilePlan<NT, NW>::PASSES; ++pass) {
+                    f4 acc[TPW];
+#pragma unroll
+                    for (int q = 0; q < TPW; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
+                    for (int p0 = 0; p0 < S; p0 += 32) {
+                        for (int kk = wave; kk < 32; kk += NW) {
+                            const int i = p0 + kk;
+                            const int j = (i - 1) >> 1;
+                            const double sgn = (i & 1) ? 1.0 : -1.0;
+#pragma unroll
+                            for (int q = 0; q < RPT; ++q) {
+                                const int t = lane + 64 * q;
+                                double v = 0.0;
+                                if (i < S) {
+                                    if (rkind[q] == 1) {
+                                        double l = (i > 0 && j <= t) ? sgn * Lp[pk(N, t, j)] : 0.0;
+                                        v = (rm[q] + (rd[q] + l)) - rr[q];
+                                    } else if (rkind[q] == 2) {
+                                        v = DR[roffs[q] + 3 * (i < rcnt[q] ? i : 0)];
+                                    }
+                                }
+                                if (rkind[q] != 3) Db[t * 32 + kk] = (__bf16)(float)v;
+                            }
+                        }
+                        __syncthreads();
+                        b8 frag[NT];
+#pragma unroll
+                        for (int I = 0; I < NT; ++I)
+                            frag[I] = *reinterpret_cast<const b8 *>(Db + (16 * I + (lane & 15)) * 32 + 8 * (lane >> 4));
+                        MfmaTiles32<NT, NW, 0>::run_bf16(frag, acc, wave, pass);
+                        __syncthreads();
+                    }
+                    MfmaTiles32<NT, NW, 0>::store(oP, N, acc, wave, lane, pass);
+                }
+            }
+            SLK_STAMP(15);
         }
     }
     if (tid == 0 && status) atomicOr(a.status + bidx, status);

@@ -155,6 +155,8 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
                 double *o = X + (size_t)i * Nq + so3_soff(L, b);
                 o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
             }
+        } else if (!pose_params_ok(a, L, a.mp ? a.mp + (size_t)bidx * a.mp_stride : nullptr)) {
+            status |= SLK_ST_BAD_INDEX;                       // pose index out of 0..2: update skipped
         } else {
             double *Z = pool;
             double *DZ = Z + round_up(S * m, 2);

@@ -20,7 +20,7 @@ HOST, DEVICE = 0, 1
 STATEK, STATEK_L, STATEK_I = 1, 2, 3
 MODEL_EXTERNAL, PM_CONST_VELOCITY, PM_DELTA_POSE, PM_DEAD_RECKON = 0, 1, 2, 3
 MM_VO_RELATIVE, MM_FEATURE_PROJ, MM_POSE_POSITION = 1, 2, 3
-ST_LLT_FAIL, ST_MEAN_NOT_CONVERGED, ST_SINGULAR, ST_ALL_REJECTED, ST_EKF_ROWS = 1, 2, 4, 8, 16
+ST_LLT_FAIL, ST_MEAN_NOT_CONVERGED, ST_SINGULAR, ST_ALL_REJECTED, ST_EKF_ROWS, ST_BAD_INDEX = 1, 2, 4, 8, 16, 32
 E_INVALID, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = -1, -2, -3, -4, -5
 
 # every symbol include/slk.h declares (checked by the CPU test-suite against the built library)
@@ -31,6 +31,7 @@ EXPORTS = [
     "slk_update_from_sigma", "slk_usckf_cloning", "slk_usckf_set_measurement", "slk_msckf_resize",
     "slk_get_outliers", "slk_get_status", "slk_clear_status", "slk_sync", "slk_timer_start", "slk_timer_stop",
     "slk_selftest_mfma", "slk_set_rebuild_precision", "slk_dead_reckon", "slk_msckf_clone_pose", "slk_msckf_drop_clone", "slk_update_ekf",
+    "slk_check_sigma_points",
 ]
 
 
@@ -87,6 +88,7 @@ def load_library(path=None):
     lib.slk_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     lib.slk_selftest_mfma.argtypes = [ip]
     lib.slk_set_rebuild_precision.argtypes = [vp, ip]
+    lib.slk_check_sigma_points.argtypes = [vp, vp, vp, ip]
     if path is None:
         _lib = lib
     return lib
@@ -129,6 +131,18 @@ def _rows(a, B, width):
     a = np.ascontiguousarray(a.reshape(a.shape[0], -1))
     assert a.shape[0] == B and a.shape[1] >= width, (a.shape, B, width)
     return _Arg(a.ctypes.data, a.shape[1], HOST, a)
+
+
+def _zrows(z, B, m):
+    """Measurement rows: the C ABI has no stride for z, slk_update / slk_step always read [B][m] doubles.  A single
+    row is therefore broadcast to every filter here (numpy), device tensors must already hold B * m values."""
+    if _is_dev(z):
+        assert z.is_contiguous() and z.numel() == B * m, (tuple(z.shape), B, m)
+        return _Arg(z.data_ptr(), m, DEVICE if z.is_cuda else HOST, z)
+    z = np.asarray(z, dtype=np.float64)
+    assert z.shape[-1] == m and (z.ndim == 1 or z.shape[0] in (1, B)), (z.shape, B, m)
+    a = np.ascontiguousarray(np.broadcast_to(z.reshape(-1, m), (B, m)))
+    return _Arg(a.ctypes.data, m, HOST, a)
 
 
 def _mat(M, B, n):
@@ -264,7 +278,7 @@ class _FilterBatch:
         """update(z, h, R), h = registered measurement model (Msckf.hpp:196-213, Usckf.hpp:246-258)."""
         m = int(z.shape[-1])
         pa = _rows(params, self.B, _np(model, m)) if _np(model, m) else _Arg(None, 0, None, None)
-        za, ra = _rows(z, self.B, m), _mat(R, self.B, m)
+        za, ra = _zrows(z, self.B, m), _mat(R, self.B, m)
         _check(self._lib.slk_update(self._h, model, pa.ptr, pa.stride, za.ptr, m, ra.ptr, ra.stride,
                                     self._default_gate(gate), _where(pa, za, ra)), "slk_update")
 
@@ -274,7 +288,7 @@ class _FilterBatch:
         ua = _rows(u, self.B, 7 if pmodel == PM_CONST_VELOCITY else 13)
         qa = _mat(Q, self.B, 12)
         pa = _rows(params, self.B, _np(mmodel, m)) if _np(mmodel, m) else _Arg(None, 0, None, None)
-        za, ra = _rows(z, self.B, m), _mat(R, self.B, m)
+        za, ra = _zrows(z, self.B, m), _mat(R, self.B, m)
         _check(self._lib.slk_step(self._h, pmodel, ua.ptr, ua.stride, qa.ptr, qa.stride, mmodel, pa.ptr, pa.stride,
                                   za.ptr, m, ra.ptr, ra.stride, self._default_gate(gate), _where(ua, qa, pa, za, ra)),
                "slk_step")
@@ -354,16 +368,24 @@ class Msckf(_FilterBatch):
             m = int(z.shape[-1])
             ra = _mat(R, self.B, m)
             assert z.is_contiguous() and zmean.is_contiguous() and H.is_contiguous()
+            assert z.numel() == self.B * m and zmean.numel() == self.B * m and H.numel() == self.B * m * self.N
             _check(self._lib.slk_update_ekf(self._h, z.data_ptr(), zmean.data_ptr(), H.data_ptr(), m, ra.ptr, ra.stride,
                                             int(bool(gate)), DEVICE), "slk_update_ekf")
             return
-        z = np.ascontiguousarray(np.atleast_2d(np.asarray(z, dtype=np.float64)))
-        zm = np.ascontiguousarray(np.atleast_2d(np.asarray(zmean, dtype=np.float64)))
-        m = z.shape[-1]
+        m = int(np.shape(z)[-1])
+        z = np.ascontiguousarray(np.broadcast_to(np.asarray(z, dtype=np.float64).reshape(-1, m), (self.B, m)))
+        zm = np.ascontiguousarray(np.broadcast_to(np.asarray(zmean, dtype=np.float64).reshape(-1, m), (self.B, m)))
         Hc = np.ascontiguousarray(np.transpose(np.asarray(H, dtype=np.float64).reshape(self.B, m, self.N), (0, 2, 1)))
         ra = _mat(np.asarray(R), self.B, m)
         _check(self._lib.slk_update_ekf(self._h, z.ctypes.data, zm.ctypes.data, Hc.ctypes.data, m, ra.ptr, ra.stride,
                                         int(bool(gate)), HOST), "slk_update_ekf")
+
+    def checkSigmaPoints(self):
+        """checkSigmaPoints() (Msckf.hpp:819-839) on the device: returns (max |covSigmaPoints - Pk| [B],
+        |mu_state [-] muX| [B]); the reference asserts <= 1e-6 and == 0 (isZero(1e-12))."""
+        ce, me = np.empty(self.B), np.empty(self.B)
+        _check(self._lib.slk_check_sigma_points(self._h, ce.ctypes.data, me.ctypes.data, HOST), "slk_check_sigma_points")
+        return ce, me
 
     def clone_pose(self):
         """Device-side muState().sensorsk.push_back(current pose) + setPk(J P J^T) (Msckf.hpp:381-395)."""
