@@ -45,6 +45,26 @@ def algorithmic_bytes(N, Nq, m, U=13):
     return 8 * (2 * N * N + 2 * Nq + m + m * m + 144 + U)
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask, cut by the cgroup CPU quota where there is one, and
+    capped at 32 so that the bounded sample stays bounded on a box that shows every core of a shared host."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:          # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = int(fq.read()), int(fp.read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return min(n, 32)
+
+
 def cpu_baseline(k, m, seed, threads=1):
     """The CPU oracle (C restatement of the reference algorithm, NOT Eigen) on a bounded sample of the same
     workload: threads = 1 is the "reference single-thread" leg; threads > 1 spreads the filters of the sample over
@@ -249,7 +269,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k, m, 0x5EED0000)
             out["speedup_vs_cpu_single_thread"] = out["value"] / out["cpu_baseline"]["value"]
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = host_cores()
             if cores > 1:
                 out["cpu_baseline_all_cores"] = cpu_baseline(k, m, 0x5EED0000, threads=cores)
                 out["speedup_vs_cpu_all_cores"] = out["value"] / out["cpu_baseline_all_cores"]["value"]

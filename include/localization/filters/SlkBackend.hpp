@@ -5,8 +5,11 @@
 #ifndef _SLK_BACKEND_HPP_
 #define _SLK_BACKEND_HPP_
 
+#include <cmath>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../slk.h"
@@ -82,6 +85,48 @@ namespace slk
     template <> struct is_registered_process<ConstVelocityModel> { enum { value = 1 }; };
     template <> struct is_registered_process<DeltaPoseModel> { enum { value = 1 }; };
     template <> struct is_registered_process<DeadReckonModel> { enum { value = 1 }; };
+
+    /** Noise arguments come as a matrix (anything with data()) or, in the reference's general overloads, as a nullary
+     *  functor returning one (boost::bind(ukfom::id<Cov>, Q): Msckf.hpp:94, :148; Usckf.hpp:164, :282). */
+    template <class T> inline auto noise_matrix(const T &q, int) -> decltype(q.data(), q) { return q; }
+    template <class T> inline auto noise_matrix(const T &q, long) -> decltype(q()) { return q(); }
+
+    /** has data() and rows(): a matrix argument (H, R), as opposed to a significance test or a noise functor */
+    template <class T> struct is_matrix_like
+    {
+        template <class U> static char test(decltype(std::declval<const U &>().data()) *, decltype(std::declval<const U &>().rows()) *);
+        template <class U> static long test(...);
+        enum { value = sizeof(test<T>(0, 0)) == sizeof(char) };
+    };
+
+    /** Significance tests (`mt`): what the caller passed as the last argument of update().
+     *  0 = accept everything, 1 = the library's chi-square gate (runs inside the kernel), 2 = any other callable
+     *  (evaluated on the host between two launches). */
+    inline int gate_kind(bool g) { return g ? 1 : 0; }
+    inline int gate_kind(int g) { return g ? 1 : 0; }
+    template <class S> inline int gate_kind(bool (*fn)(const S &, const int), bool (*builtin)(const S &, const int)) { return fn == builtin ? 1 : 2; }
+
+    /** dense inverse (Gauss-Jordan, partial pivoting) of a small host matrix -- the reference inverts the EKF information
+     *  matrix with Eigen's PartialPivLU (Msckf.hpp:765-766); host side of the custom-`mt` EKF path only */
+    inline Matrix inverse(const Matrix &A)
+    {
+        const int n = A.rows();
+        Matrix M(A), I = Matrix::Identity(n, n);
+        for (int k = 0; k < n; ++k) {
+            int p = k;
+            for (int i = k + 1; i < n; ++i) if (std::fabs(M(i, k)) > std::fabs(M(p, k))) p = i;
+            if (p != k) for (int j = 0; j < n; ++j) { std::swap(M(k, j), M(p, j)); std::swap(I(k, j), I(p, j)); }
+            const double d = M(k, k);
+            for (int j = 0; j < n; ++j) { M(k, j) /= d; I(k, j) /= d; }
+            for (int i = 0; i < n; ++i) {
+                if (i == k) continue;
+                const double f = M(i, k);
+                if (f == 0.0) continue;
+                for (int j = 0; j < n; ++j) { M(i, j) -= f * M(k, j); I(i, j) -= f * I(k, j); }
+            }
+        }
+        return I;
+    }
 
     /** column-major copy of anything with data()/rows()/cols() */
     template <class M>

@@ -3,7 +3,10 @@
  * names as the reference's src/filters/Usckf.hpp; the numerics run in libslk_hip.so.
  *
  *   Usckf(state, P0) :83-86,  Usckf(single_state, P0_single) :90-103 (places + clones twice)
- *   predict(f, Q)    :107-244   update(z, h, R[, gate]) :246-308
+ *   predict(f, Q) :107-111, predict(f, QFn) :113-244 (Q: matrix or nullary functor returning one)
+ *   update(z, h, R) :246-258, update(z, h, RFn, mt) :260-308 (mt: whole-vector significance test bool(d2); an int is the
+ *   chi-square dof of the library's own gate, 0 = ukfom::accept_any_mahalanobis_distance, the reference default :249)
+ *   updateEKF :310-319 (a stub in the reference too)   checkSigmaPoints :769-789
  *   setMeasurement   :322-389   cloning :391-433
  *   setSingleState / muSingleState / setPkSingleState / PkSingleState / muState / PkAugmentedState :435-526
  *
@@ -15,6 +18,8 @@
 #define _USCKF_HPP_
 
 #include <algorithm>
+#include <cassert>
+#include <iostream>
 #include <vector>
 
 #include "SlkBackend.hpp"
@@ -96,19 +101,22 @@ namespace localization
         template <class Cov>
         void predict(const slk::ConstVelocityModel &f, const Cov &Q)
         {
-            slk::check(slk_predict(h.get(), SLK_PM_CONST_VELOCITY, f.u, 0, Q.data(), 0, SLK_HOST), "slk_predict");
+            const auto &Qm = slk::noise_matrix(Q, 0);
+            slk::check(slk_predict(h.get(), SLK_PM_CONST_VELOCITY, f.u, 0, Qm.data(), 0, SLK_HOST), "slk_predict");
             stale = true;
         }
         template <class Cov>
         void predict(const slk::DeltaPoseModel &f, const Cov &Q)
         {
-            slk::check(slk_predict(h.get(), SLK_PM_DELTA_POSE, f.u, 0, Q.data(), 0, SLK_HOST), "slk_predict");
+            const auto &Qm = slk::noise_matrix(Q, 0);
+            slk::check(slk_predict(h.get(), SLK_PM_DELTA_POSE, f.u, 0, Qm.data(), 0, SLK_HOST), "slk_predict");
             stale = true;
         }
         template <class Cov>
         void predict(const slk::DeadReckonModel &f, const Cov &Q)
         {
-            slk::check(slk_predict(h.get(), SLK_PM_DEAD_RECKON, f.u, 0, Q.data(), 0, SLK_HOST), "slk_predict");
+            const auto &Qm = slk::noise_matrix(Q, 0);
+            slk::check(slk_predict(h.get(), SLK_PM_DEAD_RECKON, f.u, 0, Qm.data(), 0, SLK_HOST), "slk_predict");
             stale = true;
         }
         /**@brief predict with an arbitrary process model functor (the reference's boost::bind form, UsckfUnitTest.cpp:246) */
@@ -123,34 +131,91 @@ namespace localization
                 y = f(x);
                 slk_store(y, &Y[13 * i]);
             }
-            slk::check(slk_predict_from_sigma(h.get(), Y.data(), Q.data(), 0, SLK_HOST), "slk_predict_from_sigma");
+            const auto &Qm = slk::noise_matrix(Q, 0);
+            slk::check(slk_predict_from_sigma(h.get(), Y.data(), Qm.data(), 0, SLK_HOST), "slk_predict_from_sigma");
             stale = true;
         }
 
-        /**@brief UKF update with the registered relative-transform model (UsckfUnitTest.cpp:62-86); gate_dof = 0
-         * is accept_any_mahalanobis_distance (the reference default, :249) */
-        template <typename _Measurement, class Cov>
-        void update(const _Measurement &z, const slk::VoRelativeModel &, const Cov &R, int gate_dof = 0)
+        /**@brief UKF update (Usckf.hpp:246-258): accept_any_mahalanobis_distance */
+        template <typename _Measurement, typename _MeasurementModel, typename _MeasurementNoiseCovariance>
+        void update(const _Measurement &z, _MeasurementModel hfun, const _MeasurementNoiseCovariance &R)
         {
-            slk::check(slk_update(h.get(), SLK_MM_VO_RELATIVE, 0, 0, z.data(), (int)z.size(), R.data(), 0, gate_dof, SLK_HOST),
-                       "slk_update");
-            stale = true;
+            update(z, hfun, R, 0);
+        }
+        /**@brief UKF update with a significance test (Usckf.hpp:260-308), registered relative-transform model
+         * (UsckfUnitTest.cpp:62-86).  mt: int = chi-square dof of the library's gate (0 = accept any), or any callable
+         * bool(mahalanobis2) evaluated here on the innovation / covariance the GPU computed (:292-294). */
+        template <typename _Measurement, class Cov, typename _SignificanceTest>
+        void update(const _Measurement &z, const slk::VoRelativeModel &, const Cov &R, _SignificanceTest mt)
+        {
+            run_update(z, SLK_MM_VO_RELATIVE, 0, 0, slk::noise_matrix(R, 0), mt);
         }
         /**@brief UKF update with an arbitrary measurement functor h: _AugmentedState -> vector (:260-308) */
-        template <typename _Measurement, typename _MeasurementModel, class Cov>
-        void update(const _Measurement &z, _MeasurementModel hfun, const Cov &R, int gate_dof = 0)
+        template <typename _Measurement, typename _MeasurementModel, class Cov, typename _SignificanceTest>
+        void update(const _Measurement &z, _MeasurementModel hfun, const Cov &R, _SignificanceTest mt)
         {
             const int N = h.N(), Nq = h.Nq(), S = 2 * N + 1, m = (int)z.size();
             std::vector<double> X((std::size_t)S * Nq), Z((std::size_t)S * m);
             slk::check(slk_update_sigma_points(h.get(), X.data(), SLK_HOST), "slk_update_sigma_points");
             _AugmentedState x;
-            for (int i = 0; i < S; ++i) {
+            for (int i = 0; i < S; ++i) {                        // std::transform(X, Z, h), Usckf.hpp:277-278
                 slk_load(x, &X[(std::size_t)i * Nq], nfk, nfkl);
                 const _Measurement zi = hfun(x);
                 for (int r = 0; r < m; ++r) Z[(std::size_t)i * m + r] = zi[r];
             }
-            slk::check(slk_update_from_sigma(h.get(), Z.data(), z.data(), m, R.data(), 0, gate_dof, SLK_HOST), "slk_update_from_sigma");
-            stale = true;
+            run_update(z, SLK_MODEL_EXTERNAL, 0, &Z, slk::noise_matrix(R, 0), mt);
+        }
+
+        /**@brief updateEKF (Usckf.hpp:310-319): a stub in the reference (it sizes a vector, prints and returns);
+         * kept so that callers link, does nothing */
+        template <typename _Measurement, typename _MeasurementModelMatrix, typename _MeasurementNoiseCovariance>
+        void updateEKF(const _Measurement &, _MeasurementModelMatrix &, _MeasurementNoiseCovariance &) {}
+
+        /**@brief checkSigmaPoints (Usckf.hpp:769-789): the sigma points of (mu_state, Pk) are drawn on the GPU
+         * (slk_update_sigma_points); their manifold mean and covariance are folded here with the host-side state
+         * operators.  Returns whether cov == Pk (1e-6) and mean == mu_state (1e-12), reports the two errors. */
+        bool checkSigmaPoints(double &cov_err, double &mean_err)
+        {
+            pull();
+            const int N = h.N(), Nq = h.Nq(), S = 2 * N + 1;
+            std::vector<double> X((std::size_t)S * Nq);
+            slk::check(slk_update_sigma_points(h.get(), X.data(), SLK_HOST), "slk_update_sigma_points");
+            std::vector<_AugmentedState> sig(S);
+            for (int i = 0; i < S; ++i) slk_load(sig[i], &X[(std::size_t)i * Nq], nfk, nfkl);
+            _AugmentedState ref = sig[0];                        // meanSigmaPoints, :601-627
+            int it = 0;
+            double norm;
+            do {
+                slk::Vector md(N);
+                for (int i = 0; i < S; ++i) {
+                    _AugmentedState d = sig[i] - ref;
+                    const slk::Vector dv = d.getVectorizedState();
+                    for (int t = 0; t < N; ++t) md[t] += dv[t];
+                }
+                for (int t = 0; t < N; ++t) md[t] /= (double)S;
+                norm = md.norm();
+                _AugmentedState delta;
+                delta.set(md, nfk, nfkl);
+                ref = ref + delta;
+            } while (norm > 1e-6 && ++it < 10000);
+            slk::Matrix C(N, N);                                 // covSigmaPoints, :654-670
+            for (int i = 0; i < S; ++i) {
+                _AugmentedState d = sig[i] - ref;
+                const slk::Vector dv = d.getVectorizedState();
+                for (int c = 0; c < N; ++c) for (int r = 0; r < N; ++r) C(r, c) += dv[r] * dv[c];
+            }
+            cov_err = (C * 0.5 - Pk).maxAbs();
+            _AugmentedState dm = mu_state - ref;
+            mean_err = dm.getVectorizedState().norm();
+            return cov_err <= 1e-6 && mean_err <= 1e-12;
+        }
+        void checkSigmaPoints()
+        {
+            double cov_err = 0, mean_err = 0;
+            const bool ok = checkSigmaPoints(cov_err, mean_err);
+            if (cov_err > 1e-6) std::cerr << "checkSigmaPoints: max |Pktest - Pk| = " << cov_err << "\n";
+            assert(ok);
+            (void)ok;
         }
 
         /**@brief setMeasurement (Usckf.hpp:322-389) */
@@ -216,6 +281,32 @@ namespace localization
         {
             static const double thr[10] = {0, 3.84, 5.99, 7.81, 9.49, 11.07, 12.59, 14.07, 15.51, 16.92};
             return (dof >= 1 && dof <= 9) ? (mahalanobis2 < thr[dof]) : false;
+        }
+
+    private:
+        /** library gate: chi-square dof (0 = accept any) */
+        template <typename _Measurement, class Cov>
+        void run_update(const _Measurement &z, int model, const double *params, const std::vector<double> *Z, const Cov &R, int gate_dof)
+        {
+            const int m = (int)z.size();
+            if (Z) slk::check(slk_update_from_sigma(h.get(), Z->data(), z.data(), m, R.data(), 0, gate_dof, SLK_HOST), "slk_update_from_sigma");
+            else slk::check(slk_update(h.get(), model, params, 0, z.data(), m, R.data(), 0, gate_dof, SLK_HOST), "slk_update");
+            stale = true;
+        }
+        /** any other significance test bool(mahalanobis2): evaluated on the host between two launches (:292-294) */
+        template <typename _Measurement, class Cov, typename _SignificanceTest>
+        void run_update(const _Measurement &z, int model, const double *params, const std::vector<double> *Z, const Cov &R, _SignificanceTest mt)
+        {
+            const int m = (int)z.size();
+            std::vector<double> SI((std::size_t)m * m + m);
+            slk::check(slk_update_innovation(h.get(), model, params, 0, Z ? Z->data() : 0, z.data(), m, R.data(), 0, SI.data(), SLK_HOST),
+                       "slk_update_innovation");
+            slk::Matrix S(m, m);
+            slk::Vector innov(m);
+            std::copy(SI.begin(), SI.begin() + (std::size_t)m * m, S.data());
+            std::copy(SI.begin() + (std::size_t)m * m, SI.end(), innov.data());
+            const slk::Matrix d2 = innov.transpose() * (slk::inverse(S) * innov);      // :292
+            if (mt(ScalarType(d2[0]))) run_update(z, model, params, Z, R, 0);
         }
     };
 } // namespace localization

@@ -137,6 +137,21 @@ int slk_dead_reckon(slk_filter *f, const double *u, int u_stride, double *delta,
 int slk_update(slk_filter *f, int model, const double *params, int p_stride,
                const double *z, int m, const double *R, int r_stride, int gate, int where);
 
+/* ---- update(z, h, R, mt) with an ARBITRARY significance test `mt` (Msckf.hpp:220-223, Usckf.hpp:262-302): the test is a
+ *      host callable, so the update is split around it.
+ *      slk_update_innovation: sigma points, Z = h(X), innovation and S = cov(Z) + R exactly as slk_update computes them,
+ *        handed back as SI [B][m*m + m] = S (column-major), innovation; the filter is not modified.  `model` may be
+ *        SLK_MODEL_EXTERNAL with Z [B][2N+1][m] = h(X) of slk_update_sigma_points (else Z = NULL).
+ *      slk_update_selected (Msckf): the update with the surviving rows decided by the caller -- rowsel [B][m + 2] =
+ *        { number of surviving rows, number of outlier blocks, surviving row indices in order } -- instead of the built-in
+ *        chi-square loop; everything else as slk_update / slk_update_from_sigma.
+ *      (Usckf has a whole-vector test: the caller evaluates mt on S, innovation and then calls slk_update with gate 0
+ *      or not at all.) ---- */
+int slk_update_innovation(slk_filter *f, int model, const double *params, int p_stride, const double *Z,
+                          const double *z, int m, const double *R, int r_stride, double *SI, int where);
+int slk_update_selected(slk_filter *f, int model, const double *params, int p_stride, const double *Z,
+                        const double *z, int m, const double *R, int r_stride, const int *rowsel, int where);
+
 /* ---- EKF update(z, h, H, R[, mt]): Msckf.hpp:284-349 (Msckf only).  The reference's functor h(mu_state, H) is
  *      evaluated by the caller at the current mean: zmean [B][m] = h(mu), H [B][m*N] = its Jacobian, m x N column-major
  *      per filter (Eigen default), m >= N rows (reduceDimension, :791-816, compresses to N).  R as in slk_update.

@@ -615,6 +615,58 @@ int slk_update_from_sigma(slk_filter *f, const double *Z, const double *z, int m
     return launch(f, a);
 }
 
+int slk_update_innovation(slk_filter *f, int model, const double *params, int p_stride, const double *Z,
+                          const double *z, int m, const double *R, int r_stride, double *SI, int where)
+{
+    if (!f || !SI) return SLK_E_INVALID;
+    if ((model == SLK_MODEL_EXTERNAL) != (Z != nullptr)) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    KArgs a;
+    base_args(f, a);
+    int rc = fill_update(f, a, model, params, p_stride, z, m, R, r_stride, 0, where);
+    if (rc) return rc;
+    if (Z) { rc = stage_in(f, f->st_Z, Z, (size_t)f->B * (2 * f->lay.N + 1) * m, where, &a.Zext); if (rc) return rc; }
+    const size_t n = (size_t)f->B * (m * m + m);
+    a.emit = 4;
+    if (where == SLK_DEVICE) a.Xout = SI;
+    else { rc = stage_reserve(f, f->st_X, n); if (rc) return rc; a.Xout = f->st_X.p; }
+    rc = launch(f, a);
+    if (rc) return rc;
+    if (where == SLK_HOST) {
+        HIPCHECK(hipMemcpyAsync(SI, a.Xout, n * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+        HIPCHECK(hipStreamSynchronize(f->stream));
+    }
+    return SLK_OK;
+}
+
+int slk_update_selected(slk_filter *f, int model, const double *params, int p_stride, const double *Z,
+                        const double *z, int m, const double *R, int r_stride, const int *rowsel, int where)
+{
+    if (!f || f->lay.kind != SLK_MSCKF || !rowsel) return SLK_E_INVALID;
+    if ((model == SLK_MODEL_EXTERNAL) != (Z != nullptr)) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    KArgs a;
+    base_args(f, a);
+    int rc = fill_update(f, a, model, params, p_stride, z, m, R, r_stride, 2, where);
+    if (rc) return rc;
+    if (Z) { rc = stage_in(f, f->st_Z, Z, (size_t)f->B * (2 * f->lay.N + 1) * m, where, &a.Zext); if (rc) return rc; }
+    const size_t n = (size_t)f->B * (m + 2);
+    if (where == SLK_DEVICE) {
+        a.rowsel = rowsel;
+    } else {
+        for (size_t b = 0; b < (size_t)f->B; ++b) {                 // host data: validate before it reaches the kernel
+            const int *rs = rowsel + b * (m + 2);
+            if (rs[0] < 0 || rs[0] > m || rs[1] < 0) return SLK_E_INVALID;
+            for (int r = 0; r < rs[0]; ++r) if (rs[2 + r] < 0 || rs[2 + r] >= m) return SLK_E_INVALID;
+        }
+        rc = stage_reserve(f, f->st_tmpM, (n * sizeof(int) + sizeof(double) - 1) / sizeof(double));
+        if (rc) return rc;
+        HIPCHECK(hipMemcpyAsync(f->st_tmpM.p, rowsel, n * sizeof(int), hipMemcpyHostToDevice, f->stream));
+        a.rowsel = reinterpret_cast<const int *>(f->st_tmpM.p);
+    }
+    return launch(f, a);
+}
+
 int slk_get_outliers(slk_filter *f, unsigned *outliers, int where)
 {
     if (!f || !outliers) return SLK_E_INVALID;

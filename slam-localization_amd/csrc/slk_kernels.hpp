@@ -35,6 +35,7 @@ struct KArgs {
     // update
     int do_update, mm; const double *mp; int mp_stride; const double *z; int m;
     const double *R; int r_stride; int gate; const double *Zext;
+    const int *rowsel;    // gate == 2: [B][m + 2] = surviving rows, outliers, row indices (device)
     // tier B sigma-point emission: 1 = predict sigma points, 2 = update sigma points
     int emit; double *Xout;     // 3 = checkSigmaPoints: re-draw, mean and covariance into mean_out / P_out
     double *mean_out, *P_out;   // null = in place
@@ -1301,7 +1302,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
     double *omean = a.mean_out ? a.mean_out + (size_t)bidx * Nq : gmean;     // where applyDelta's results go
     double *oP = a.P_out ? a.P_out + (size_t)bidx * N * N : gP;
     int status = 0;
-    if (a.do_update && tid == 0) a.outliers[bidx] = 0u;
+    if (a.do_update && a.emit != 4 && tid == 0) a.outliers[bidx] = 0u;
     SLK_STAMP(0);
 
     for (int e = tid; e < Nq; e += NTHREADS) mu[e] = gmean[e];
@@ -1415,6 +1416,15 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 unsigned nout = 0;
                 for (int r = 0; r < m; ++r) idx[r] = r;
                 int i = 0;
+                if (a.gate == 2) {
+                    // the caller ran the significance test itself (an arbitrary `mt`, Msckf.hpp:220-223) on the
+                    // innovation / covariance of an emit-4 launch: rowsel = { surviving rows, outliers, row indices }
+                    const int *rs = a.rowsel + (size_t)bidx * (m + 2);
+                    cnt = rs[0] < 0 ? 0 : (rs[0] > m ? m : rs[0]);
+                    nout = (unsigned)rs[1];
+                    for (int r = 0; r < cnt; ++r) { int v = rs[2 + r]; idx[r] = v < 0 ? 0 : (v >= m ? m - 1 : v); }
+                    i = cnt;                                       // skip the built-in loop
+                }
                 while (i < cnt / 2) {
                     int p = idx[2 * i], q = idx[2 * i + 1];
                     double s00 = Sm[p + m * p], s01 = Sm[p + m * q], s10 = Sm[q + m * p], s11 = Sm[q + m * q];
@@ -1438,8 +1448,13 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
             __syncthreads();
             SLK_STAMP(7);
             const int mmr = ish[40];
-            if (tid == 0) a.outliers[bidx] = (unsigned)ish[41];
-            if (mmr == 0) {
+            if (tid == 0 && a.emit != 4) a.outliers[bidx] = (unsigned)ish[41];
+            if (a.emit == 4) {
+                // innovation and its covariance for a caller-side significance test: Xout [B][m*m + m]
+                double *o = a.Xout + (size_t)bidx * (m * m + m);
+                for (int e = tid; e < m * m; e += NTHREADS) o[e] = Sm[e];
+                for (int e = tid; e < m; e += NTHREADS) o[m * m + e] = innov[e];
+            } else if (mmr == 0) {
                 status |= SLK_ST_ALL_REJECTED;                         // :250, nothing applied
             } else {
                 // K = covXZ * S^-1 (:257).  S = 1/2 dZ dZ^T + R is symmetric positive definite for any

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
     double *gmean = a.mean + (size_t)bidx * Nq;
     double *gP = a.P + (size_t)bidx * N * N;
     int status = 0;
-    if (a.do_update && tid == 0) a.outliers[bidx] = 0u;
+    if (a.do_update && a.emit != 4 && tid == 0) a.outliers[bidx] = 0u;
     if (tid == 0) ish[42] = 0;
 
     for (int e = tid; e < Nq; e += NTHREADS) mu[e] = gmean[e];
@@ -170,8 +170,15 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
             double *dlt = wv + 2 * round_up(m, 2);
             measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lm, Z, DZ, Pxz, Sm, zbar, innov, &ish[42],
                                            [&](int t) { return P[t + t * lda]; });
+            if (a.emit == 4) {
+                // innovation and its covariance for a caller-side significance test (Usckf.hpp:262-302 with an
+                // arbitrary `mt`): Xout [B][m*m + m] = S (column-major), innovation; nothing else happens
+                double *o = a.Xout + (size_t)bidx * (m * m + m);
+                for (int e = tid; e < m * m; e += NTHREADS) o[e] = Sm[e];
+                for (int e = tid; e < m; e += NTHREADS) o[m * m + e] = innov[e];
+            }
             // S^-1 (:285-286): S = 1/2 dZ dZ^T + R is SPD for a valid R -> Cholesky, row-wise solves
-            if (wave == 0) {
+            if (a.emit != 4 && wave == 0) {
                 auto sel = [&](int i, int j) { return Sm[i + m * j]; };
                 int f0;
                 if (m <= 16) {
@@ -187,7 +194,8 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
             }
             __syncthreads();
             const int sfail = ish[46];
-            if (sfail >= 0) {
+            if (a.emit == 4) {
+            } else if (sfail >= 0) {
                 status |= SLK_ST_SINGULAR;
             } else {
                 for (int t = tid; t < N; t += NTHREADS) {             // K = covXZ * S^-1 :288
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
             }
         }
         __syncthreads();
-        if (a.emit != 2 && (applied || a.do_predict)) {
+        if (a.emit != 2 && a.emit != 4 && (applied || a.do_predict)) {
             for (int c = wave; c < N; c += NW)
                 for (int r = lane; r < N; r += 64) gP[r + (size_t)c * N] = P[r + c * lda];
             for (int e = tid; e < Nq; e += NTHREADS) gmean[e] = mu[e];

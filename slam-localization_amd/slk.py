@@ -31,7 +31,7 @@ EXPORTS = [
     "slk_update_from_sigma", "slk_usckf_cloning", "slk_usckf_set_measurement", "slk_msckf_resize",
     "slk_get_outliers", "slk_get_status", "slk_clear_status", "slk_sync", "slk_timer_start", "slk_timer_stop",
     "slk_selftest_mfma", "slk_set_rebuild_precision", "slk_dead_reckon", "slk_msckf_clone_pose", "slk_msckf_drop_clone", "slk_update_ekf",
-    "slk_check_sigma_points",
+    "slk_check_sigma_points", "slk_update_innovation", "slk_update_selected",
 ]
 
 

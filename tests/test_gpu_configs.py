@@ -214,7 +214,7 @@ def test_shared_measurement_row_is_broadcast(slk):
     s["P"][:] = s["P"][0]
     a = slk.Msckf(s["mean"], s["P"])
     b = slk.Msckf(s["mean"], s["P"])
-    a.update(s["z"][0], slk.MM_FEATURE_PROJ, s["feat"][0], s["R"])
+    a.update(s["z"][0], slk.MM_FEATURE_PROJ, s["feat"][0].reshape(-1), s["R"])
     b.update(np.tile(s["z"][0], (3, 1)), slk.MM_FEATURE_PROJ, np.tile(s["feat"][0], (3, 1, 1)), s["R"])
     np.testing.assert_array_equal(a.getPk(), b.getPk())
     np.testing.assert_array_equal(a.getPk()[0], a.getPk()[2])

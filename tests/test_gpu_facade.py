@@ -85,3 +85,82 @@ def test_ekf_update_through_cpp_facade(res):
     assert st == 0 and no == int(res["ekf_outliers"][0, 0]) and no >= 1
     assert rel(res["ekf_P"], f.P) <= TOL
     assert np.abs(o.boxminus(lay, res["ekf_mean"][:, 0], f.mean)).max() <= TOL
+
+
+# ------------------------------------------------------------------ the reference's own model functions
+@pytest.fixture(scope="module")
+def ref():
+    import __graft_entry__ as ge
+    ge.build()
+    import facade_build
+    return facade_build.run(name="reference_models", std="c++14")
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_reference_process_model_and_significance_tests_through_facade(ref, tag):
+    """tests/cpp/reference_models.cpp: processModel of test/MsckfUnitTest.cpp:33-47 pasted unchanged, bound with
+    std::bind like the reference's boost::bind (:200-205); variants a = predict(f, Q) + update(z, h, R), b = predict(f, QFn,
+    Nk) + update(z, h, R, accept_mahalanobis_distance), c = ... + update with an arbitrary callable mt."""
+    g = np.load(os.path.join(G, "msckf_unit_test.npz"))
+    k = 4
+    lay = o.layout(o.MULTI, k)
+    for i in range(2):
+        assert rel(ref[f"ref_msckf_{tag}_pred{i}_P"], g[f"k{k}_pred{i}_P"]) <= TOL
+        assert np.abs(o.boxminus(lay, ref[f"ref_msckf_{tag}_pred{i}_mean"][:, 0], g[f"k{k}_pred{i}_mean"])).max() <= TOL
+    assert ref[f"ref_msckf_{tag}_check_ok"][0, 0] == 1 and ref[f"ref_msckf_{tag}_check_cov"][0, 0] <= 1e-12
+    assert ref[f"ref_msckf_{tag}_check_mean"][0, 0] <= 1e-12
+    # the update (third feature a gross outlier) against the oracle from the predicted golden state
+    r = o.Msckf(k, g[f"k{k}_pred1_mean"], g[f"k{k}_pred1_P"])
+    feat = g[f"k{k}_feat"].copy()
+    z = g[f"k{k}_z"].copy()
+    z[4] += 3.0
+    st, no = r.update(z, o.mm_feature_proj(feat), 0.01 * np.eye(8))
+    assert st == 0 and no == 1 == int(ref[f"ref_msckf_{tag}_outliers"][0, 0])
+    assert int(ref[f"ref_msckf_{tag}_status"][0, 0]) == 0
+    assert rel(ref[f"ref_msckf_{tag}_upd_P"], r.P) <= TOL
+    assert np.abs(o.boxminus(lay, ref[f"ref_msckf_{tag}_upd_mean"][:, 0], r.mean)).max() <= TOL
+    # the arbitrary callable really ran on the host: once per block it looked at (4 blocks, one rejected -> 4 calls)
+    assert int(ref[f"ref_msckf_{tag}_mt_calls"][0, 0]) == (4 if tag == "c" else 0)
+    for key in ("upd_P", "upd_mean"):
+        np.testing.assert_array_equal(ref[f"ref_msckf_{tag}_{key}"], ref[f"ref_msckf_a_{key}"])
+
+
+def test_nonconst_mustate_window_edit_through_facade(ref):
+    """Msckf.hpp:381-395: muState().sensorsk.push_back(...) + setPk(...) == a fresh filter built from the edited state."""
+    np.testing.assert_array_equal(ref["ref_window_P"], ref["ref_window_fresh_P"])
+    np.testing.assert_array_equal(ref["ref_window_mean"], ref["ref_window_fresh_mean"])
+    assert ref["ref_window_P"].shape == (24, 24)
+
+
+def test_reference_usckf_models_through_facade(ref):
+    """processModel / measurementModelVO of test/UsckfUnitTest.cpp:34-86 pasted unchanged (functor path) == registered
+    models on the GPU == the oracle, on an SPD state of the unit-test shape; update(z, h, RFn, mt) with a callable."""
+    nfk, nfkl, N = 3, 9, 48
+    mean = np.zeros(39 + nfk + nfkl)
+    for b in range(3):
+        s = 13 * b
+        mean[s:s + 3] = [0.5 + 0.1 * b, -0.3 + 0.05 * b, 1.0 - 0.2 * b]
+        mean[s + 3:s + 7] = o.so3_exp(np.array([0.05 * (b + 1), -0.04 * b, 0.03 + 0.02 * b]))
+        mean[s + 7:s + 10] = [0.3, -0.1 * b, 0.2]
+        mean[s + 10:s + 13] = [0.01 * b, 0.02, -0.01]
+    mean[39:42] = 2.0 + 0.5 * np.arange(3)
+    mean[42:51] = 1.0 + 0.25 * np.arange(9)
+    i, j = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+    A = 0.007 * (((i * 7 + j * 13) % 11) - 5.0) / 5.0
+    P = A @ A.T + 0.0025 * np.eye(N)
+    D2R = np.pi / 180
+    f = o.Usckf(nfk=nfk, nfkl=nfkl, mean=mean, P=P)
+    pm = o.pm_const_velocity(np.array([1.0, 0.1, -0.2]), np.array([10 * D2R, -5 * D2R, 8 * D2R]), 0.01)
+    z = np.array([2.05, 2.45, 3.1])
+    for _ in range(2):
+        assert f.predict(pm, 0.1 * 0.01 * np.eye(12)) == 0
+        st, acc = f.update(z, o.mm_vo_relative(), 0.01 * np.eye(3))
+        assert st == 0 and acc == 1
+    lay = o.layout(o.AUGMENTED, 0, nfk, nfkl)
+    for tag in ("model", "functor", "mt"):
+        assert int(ref[f"ref_usckf_{tag}_status"][0, 0]) == 0
+        assert rel(ref[f"ref_usckf_{tag}_P"], f.P) <= TOL, tag
+        assert np.abs(o.boxminus(lay, ref[f"ref_usckf_{tag}_mean"][:, 0], f.mean)).max() <= TOL, tag
+        assert ref[f"ref_usckf_{tag}_check_ok"][0, 0] == 1 and ref[f"ref_usckf_{tag}_check_cov"][0, 0] <= 1e-10
+    assert int(ref["ref_usckf_mt_mt_calls"][0, 0]) == 2
+    assert ref["ref_usckf_rejected_unchanged"][0, 0] == 1
