@@ -129,6 +129,39 @@ int slk_predict(slk_filter *f, int model, const double *u, int u_stride,
  *      (cov_position = C_vv dt^2, cov_orientation = C_ww dt^2, :167-176) is a scaling left to the caller. ---- */
 int slk_dead_reckon(slk_filter *f, const double *u, int u_stride, double *delta, int where);
 
+/* ---- TransformWithUncertainty::operator* (src/core/Transform.cpp:215-254; Jacobians of Pennec & Thirion :35-137) for the
+ *      batch: out = t2 * t1 with transforms [B][7] = pos[3] quat[4: x,y,z,w] and covariances [B][36] = 6x6 column-major
+ *      in the reference's [r t] order (rotation as a scaled axis first, translation second; Transform.hpp:57-61).
+ *      cov2 / cov1 NULL = that side carries no uncertainty (hasUncertainty() false).  additive != 0 is the other branch
+ *      of DeadReckon::updatePose's Affine3d overload (src/core/DeadReckon.hpp:306-330): pose = t2 * t1, covariance =
+ *      cov2 + cov1 (t2 = prevPose, t1 = deltaPose there).  cov_out may be NULL. ---- */
+int slk_transform_compose(slk_filter *f, const double *t2, const double *cov2, const double *t1, const double *cov1,
+                          double *t_out, double *cov_out, int additive, int where);
+
+/* ---- DeadReckon::updatePose, RigidBodyState overload (src/core/DeadReckon.hpp:129-239), whole: delta pose AND the
+ *      covariance / posterior legs (:165-176, :200-229), for the batch.
+ *      u [B][u_stride] as in slk_dead_reckon; velcov 6x6 column-major (linear 0-2, angular 3-5), c_stride 0 = shared;
+ *      an entry that is NaN zeroes the delta covariances (:165-176).
+ *      prev  [B][25] = pos[3] quat[4] cov_position[9] cov_orientation[9]            (3x3 column-major)
+ *      post  [B][49] = the same 25 + velocity[3] cov_velocity[9] angular_velocity[3] cov_angular_velocity[9]; IN/OUT:
+ *                      without use_tf the reference ACCUMULATES into it (position +=, covariances +=, :219-222)
+ *      delta [B][31] = pose record (25) + velocity[3] angular_velocity[3]; may be NULL.  delta[0:7] + [25:31] is the `u` of
+ *                      SLK_PM_DELTA_POSE.
+ *      use_tf != 0: tfPostPose = tfPrevPose * tfDeltaPose through slk_transform_compose's arithmetic (:202-215). ---- */
+int slk_dead_reckon_pose(slk_filter *f, const double *u, int u_stride, const double *velcov, int c_stride,
+                         const double *prev, double *post, double *delta, int use_tf, int where);
+
+/* ---- AdaptiveAttitudeCov (src/filters/MeasurementModels.hpp:136-286): a batch of B independent objects (history of
+ *      m1 residual outer products, r1count, r2count each) resident on the device.  slk_adaptive_matrix is one call of
+ *      ::matrix(xk, Pk, z, H, R) per object: xk [B][n], Pk [B][n*n], z [B][3], H [B][3*n] (3 x n column-major),
+ *      R 3x3 (r_stride 0 = shared) -> Rout [B][9], which is the R (r_stride 9) of slk_update / slk_step. ---- */
+typedef struct slk_adaptive slk_adaptive;
+int  slk_adaptive_create(int batch, int device, unsigned m1, unsigned m2, double gamma, unsigned r2count, void *stream,
+                         slk_adaptive **out);
+void slk_adaptive_destroy(slk_adaptive *a);
+int  slk_adaptive_matrix(slk_adaptive *a, int n, const double *xk, const double *Pk, const double *z, const double *H,
+                         const double *R, int r_stride, double *Rout, int where);
+
 /* ---- update(z, h, R[, mt]): UKF update, Msckf.hpp:196-277 (chi-square gate per 2-row block
  *      + applyDelta re-draw) and Usckf.hpp:246-308 (whole-vector gate, direct boxplus).
  *      params [B][p_stride] model parameters (0 = shared), z [B][m], R m x m (r_stride 0 = shared).

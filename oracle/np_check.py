@@ -320,3 +320,128 @@ class Usckf:
         K = (0.5 * D.T @ dZ) @ np.linalg.inv(S)
         self.P = self.P - K @ S @ K.T
         self.mean = man.plus(self.mean, K @ (np.asarray(z, dtype=float) - zbar))
+
+
+# ---------------------------------------------------------------- TransformWithUncertainty / DeadReckon pose legs
+# Independent of slk_oracle.c: scipy Rotation for every rotation conversion, numpy block algebra for the Jacobians of
+# Pennec & Thirion as src/core/Transform.cpp:35-137 writes them.  Quaternions inside the Jacobians are (w, x, y, z).
+def _canon(q_xyzw):
+    """the quaternion Eigen derives from a rotation matrix on the trace > 0 branch (w > 0)"""
+    q = Rot.from_quat(q_xyzw).as_quat()
+    return q if q[3] >= 0 else -q
+
+
+def _rvec(q_xyzw):
+    """q_to_r (Transform.cpp:44-48): axis * angle with the angle in [0, pi]"""
+    return Rot.from_quat(q_xyzw).as_rotvec()
+
+
+def _skew(r):
+    return np.array([[0.0, -r[2], r[1]], [r[2], 0.0, -r[0]], [-r[1], r[0], 0.0]])
+
+
+def _dq_by_dr(q):
+    r = _rvec(q)
+    th2 = float(r @ r)
+    return np.vstack([-q[:3] / 2.0, (0.5 - th2 / 48.0) * np.eye(3) - (1.0 / 24.0) * (1.0 - th2 / 40.0) * np.outer(r, r)])
+
+
+def _dr_by_dq(q):
+    v = q[:3]
+    mu2 = float(v @ v)
+    sg = 1.0 if q[3] > 0 else -1.0
+    tau, nu = 2.0 * sg * (1.0 + mu2 / 6.0), -2.0 * sg * (2.0 / 3.0 + mu2 / 5.0)
+    return np.hstack([(-2.0 * v)[:, None], tau * np.eye(3) + nu * np.outer(v, v)])
+
+
+def _dq2q1(q, sgn):
+    v = q[:3]
+    M = np.zeros((4, 4))
+    M[0, 1:], M[1:, 0], M[1:, 1:] = -v, v, sgn * _skew(v)
+    return q[3] * np.eye(4) + M
+
+
+def _drx_by_dr(q, x):
+    r = _rvec(q)
+    th2 = float(r @ r)
+    al, be, ga, de = 1.0 - th2 / 6.0, 0.5 - th2 / 24.0, 1.0 / 3.0 - th2 / 30.0, -1.0 / 12.0 + th2 / 180.0
+    rr, Sx, Sr = np.outer(r, r), _skew(x), _skew(r)
+    return -Sx @ (ga * rr - be * Sr + al * np.eye(3)) - Sr @ Sx @ (de * rr + 2.0 * be * np.eye(3))
+
+
+def transform_compose(t2, cov2, t1, cov1):
+    """TransformWithUncertainty::operator* (Transform.cpp:215-254): t = pos[3] quat[4], cov 6x6 [r t] or None."""
+    t2, t1 = np.asarray(t2, float), np.asarray(t1, float)
+    R2, R1 = Rot.from_quat(t2[3:7]), Rot.from_quat(t1[3:7])
+    out = np.concatenate([R2.apply(t1[0:3]) + t2[0:3], _canon((R2 * R1).as_quat())])
+    cov = np.zeros((6, 6))
+    if cov1 is None and cov2 is None:
+        return out, cov
+    q1, q2 = _canon(t1[3:7]), _canon(t2[3:7])
+    q = (Rot.from_quat(q2) * Rot.from_quat(q1)).as_quat()
+    if np.dot(q, np.r_[q2[3] * q1[:3] + q1[3] * q2[:3] + np.cross(q2[:3], q1[:3]), q2[3] * q1[3] - q2[:3] @ q1[:3]]) < 0:
+        q = -q                                                   # the plain product q2 * q1 (no canonicalisation)
+    if cov1 is not None:
+        J1 = np.zeros((6, 6))
+        J1[:3, :3] = _dr_by_dq(q) @ _dq2q1(q2, 1.0) @ _dq_by_dr(q1)
+        J1[3:, 3:] = R2.as_matrix()
+        cov += J1 @ np.asarray(cov1, float) @ J1.T
+    if cov2 is not None:
+        J2 = np.eye(6)
+        J2[:3, :3] = _dr_by_dq(q) @ _dq2q1(q1, -1.0) @ _dq_by_dr(q2)
+        J2[3:, :3] = _drx_by_dr(q2, t1[0:3])
+        cov += J2 @ np.asarray(cov2, float) @ J2.T
+    return out, cov
+
+
+def dead_reckon_pose(u, velcov, prev, post, use_tf):
+    """DeadReckon::updatePose, RigidBodyState overload (DeadReckon.hpp:129-239); records as in slk_oracle.c."""
+    u, velcov, prev, post = (np.asarray(a, float) for a in (u, velcov, prev, post))
+    dt = u[0]
+    d13 = dead_reckon_delta(u)
+    nan = np.isnan(velcov).any()
+    cp = np.zeros((3, 3)) if nan else velcov[:3, :3] * dt * dt
+    co = np.zeros((3, 3)) if nan else velcov[3:, 3:] * dt * dt
+    delta = np.concatenate([d13[0:7], cp.T.ravel(), co.T.ravel(), d13[7:10], d13[10:13]])
+    out = post.copy()
+    pcp, pco = prev[7:16].reshape(3, 3).T, prev[16:25].reshape(3, 3).T
+    if use_tf:
+        z = np.zeros((3, 3))
+        t, c = transform_compose(prev[0:7], np.block([[pco, z], [z, pcp]]), d13[0:7], np.block([[co, z], [z, cp]]))
+        out[0:7] = t
+        out[16:25], out[7:16] = c[:3, :3].T.ravel(), c[3:, 3:].T.ravel()
+    else:
+        out[0:3] = post[0:3] + Rot.from_quat(prev[3:7]).apply(d13[0:3])
+        out[7:16] = post[7:16] + cp.T.ravel()
+        out[16:25] = post[16:25] + co.T.ravel()
+        qa, qb = prev[3:7], d13[3:7]
+        out[3:7] = np.r_[qa[3] * qb[:3] + qb[3] * qa[:3] + np.cross(qa[:3], qb[:3]), qa[3] * qb[3] - qa[:3] @ qb[:3]]
+    out[25:28], out[37:40] = u[1:4], u[4:7]
+    out[28:37], out[40:49] = velcov[:3, :3].T.ravel(), velcov[3:, 3:].T.ravel()
+    return out, delta
+
+
+class AdaptiveAttitudeCov:
+    """AdaptiveAttitudeCov (src/filters/MeasurementModels.hpp:136-286) with numpy.linalg.svd in the place of JacobiSVD."""
+
+    def __init__(self, m1, m2, gamma, r2count):
+        self.m1, self.m2, self.gamma, self.r1count, self.r2count = m1, m2, gamma, 0, r2count
+        self.hist = np.zeros((m1, 3, 3))
+
+    def matrix(self, xk, Pk, z, H, R):
+        res = z - H @ xk
+        self.hist[self.r1count] = np.outer(res, res)
+        self.r1count = (self.r1count + 1) % self.m1
+        Uk = self.hist.sum(axis=0) / self.m1
+        fooR = H @ Pk @ H.T + R
+        u, s, _ = np.linalg.svd(Uk)
+        mu = np.array([u[:, c] @ fooR @ u[:, c] for c in range(3)])
+        w = np.maximum(s - mu, 0.0)
+        if (s - mu).max() > self.gamma:
+            self.r2count = 0
+            use = True
+        else:
+            self.r2count += 1
+            use = self.r2count < self.m2
+        Q = sum(w[c] * np.outer(u[:, c], u[:, c]) for c in range(3)) if use else np.zeros((3, 3))
+        return R + Q

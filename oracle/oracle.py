@@ -427,3 +427,65 @@ def msckf_step_batch(k, m, steps, mean, P, u, feat, z, Q, R, gate=True):
     st = lib().slko_msckf_step_batch(B, k, m, steps, _p(mean), _p(P), _p(u), _p(feat), _p(z), _p(_colmajor(Q)),
                                      _p(_colmajor(R)), int(gate), out.ctypes.data_as(C.POINTER(C.c_uint)))
     return st, out
+
+
+# ---------------------------------------------------------------- f3 / f4 batch helpers
+def transform_compose(t2, cov2, t1, cov1):
+    """TransformWithUncertainty::operator* (src/core/Transform.cpp:215-254): -> (t [7], cov [6, 6])."""
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    L.slko_transform_compose.argtypes = [dp, dp, dp, dp, dp, dp]
+    L.slko_transform_compose.restype = None
+    t2, t1 = _arr(t2, 7), _arr(t1, 7)
+    c2 = _colmajor(cov2) if cov2 is not None else None
+    c1 = _colmajor(cov1) if cov1 is not None else None
+    out, oc = np.zeros(7), np.zeros(36)
+    L.slko_transform_compose(_p(t2), _p(c2) if c2 is not None else None, _p(t1), _p(c1) if c1 is not None else None,
+                             _p(out), _p(oc))
+    return out, _from_colmajor(oc, 6, 6)
+
+
+def update_pose_affine(prev, prev_cov, delta, delta_cov, use_tf):
+    """DeadReckon::updatePose, Affine3d overload (src/core/DeadReckon.hpp:306-330)."""
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    L.slko_update_pose_affine.argtypes = [dp, dp, dp, dp, C.c_int, dp, dp]
+    L.slko_update_pose_affine.restype = None
+    out, oc = np.zeros(7), np.zeros(36)
+    L.slko_update_pose_affine(_p(_arr(prev, 7)), _p(_colmajor(prev_cov)), _p(_arr(delta, 7)), _p(_colmajor(delta_cov)),
+                              int(use_tf), _p(out), _p(oc))
+    return out, _from_colmajor(oc, 6, 6)
+
+
+def dead_reckon_pose(u, velcov, prev, post, use_tf):
+    """DeadReckon::updatePose, RigidBodyState overload (src/core/DeadReckon.hpp:129-239): -> (post [49], delta [31])."""
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    L.slko_dead_reckon_pose.argtypes = [dp, dp, dp, dp, dp, C.c_int]
+    L.slko_dead_reckon_pose.restype = None
+    po, de = _arr(post, 49).copy(), np.zeros(31)
+    L.slko_dead_reckon_pose(_p(_arr(u, 13)), _p(_colmajor(velcov)), _p(_arr(prev, 25)), _p(po), _p(de), int(use_tf))
+    return po, de
+
+
+class AdaptiveAttitudeCov:
+    """AdaptiveAttitudeCov (src/filters/MeasurementModels.hpp:136-286), one object per filter like the reference."""
+
+    def __init__(self, m1, m2, gamma, r2count):
+        self.m1, self.m2, self.gamma = m1, m2, gamma
+        self.hist = np.zeros(m1 * 9)
+        self.r1 = C.c_uint(0)
+        self.r2 = C.c_uint(r2count)
+
+    def matrix(self, xk, Pk, z, H, R):
+        L = lib()
+        dp = C.POINTER(C.c_double)
+        up = C.POINTER(C.c_uint)
+        L.slko_adaptive_attitude_cov.argtypes = [C.c_uint, C.c_uint, C.c_double, dp, up, up, C.c_int, dp, dp, dp, dp, dp, dp]
+        L.slko_adaptive_attitude_cov.restype = None
+        n = len(xk)
+        out = np.zeros(9)
+        L.slko_adaptive_attitude_cov(self.m1, self.m2, self.gamma, _p(self.hist), C.byref(self.r1), C.byref(self.r2), n,
+                                     _p(_arr(xk, n)), _p(_colmajor(np.asarray(Pk).reshape(n, n))), _p(_arr(z, 3)),
+                                     _p(_colmajor(np.asarray(H).reshape(3, n))), _p(_colmajor(R)), _p(out))
+        return _from_colmajor(out, 3, 3)

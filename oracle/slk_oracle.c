@@ -1228,3 +1228,360 @@ int slko_msckf_step_batch(int B, int k, int m, int steps, double *mean, double *
     }
     return status;
 }
+
+/* ====================================================================== */
+/* TransformWithUncertainty (src/core/Transform.cpp) and the pose legs of */
+/* DeadReckon::updatePose (src/core/DeadReckon.hpp:129-239, :306-330)     */
+/* ====================================================================== */
+/* A transform is stored as pos[3] quat[4: x,y,z,w]; the reference keeps an Eigen::Affine3d and derives quaternions
+ * from its rotation matrix (Eigen::Quaterniond(linear()), Transform.cpp:222-225), which is restated here (Eigen
+ * Quaternion.h, quaternionbase_assign_impl<Other,3,3>).  6x6 covariances are column-major in the [r t] order of
+ * the reference (rotation as a scaled axis first, translation second; Transform.hpp:57-61).  3x3 helpers are
+ * ROW-major m[3*i + j] internally. */
+
+static void quat_to_rot(const double q[4], double R[9])            /* Eigen QuaternionBase::toRotationMatrix */
+{
+    double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+static void rot_to_quat(const double m[9], double q[4])            /* Eigen: rotation matrix -> quaternion */
+{
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[3 * 2 + 1] - m[3 * 1 + 2]) * t;
+        q[1] = (m[3 * 0 + 2] - m[3 * 2 + 0]) * t;
+        q[2] = (m[3 * 1 + 0] - m[3 * 0 + 1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[3 * i + i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[3 * i + i] - m[3 * j + j] - m[3 * k + k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+        q[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+        q[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    }
+}
+
+/* q_to_r, Transform.cpp:44-48: Eigen::AngleAxisd(q) (Eigen 3.3: angle = 2 atan2(|vec|, |w|), axis = vec / (+-|vec|)) */
+static void q_to_r(const double q[4], double r[3])
+{
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    if (n != 0) {
+        double angle = 2 * atan2(n, fabs(q[3]));
+        if (q[3] < 0) n = -n;
+        r[0] = q[0] / n * angle; r[1] = q[1] / n * angle; r[2] = q[2] / n * angle;
+    } else { r[0] = r[1] = r[2] = 0; }                              /* angle 0 times the axis (1, 0, 0) */
+}
+
+static double sign_of(double v) { return v > 0 ? 1.0 : -1.0; }     /* Transform.cpp:50-53 */
+
+static void skew(const double r[3], double S[9])                  /* Transform.cpp:55-62 */
+{
+    S[0] = 0; S[1] = -r[2]; S[2] = r[1];
+    S[3] = r[2]; S[4] = 0; S[5] = -r[0];
+    S[6] = -r[1]; S[7] = r[0]; S[8] = 0;
+}
+
+static void mat_mul(int n, int k, int m, const double *A, const double *B, double *C)   /* row-major (n x k)(k x m) */
+{
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < m; ++j) {
+            double s = 0;
+            for (int p = 0; p < k; ++p) s += A[i * k + p] * B[p * m + j];
+            C[i * m + j] = s;
+        }
+}
+
+/* dq_by_dr, Transform.cpp:64-76: 4 x 3, quaternion ordered (w, x, y, z) */
+static void dq_by_dr(const double q[4], double D[12])
+{
+    double r[3];
+    q_to_r(q, r);
+    double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    double kappa = 0.5 - theta * theta / 48.0;
+    double lambda = 1.0 / 24.0 * (1.0 - theta * theta / 40.0);
+    for (int j = 0; j < 3; ++j) D[j] = -q[j] / 2.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) D[3 * (i + 1) + j] = kappa * (i == j) - lambda * r[i] * r[j];
+}
+
+/* dr_by_dq, Transform.cpp:78-89: 3 x 4 */
+static void dr_by_dq(const double q[4], double D[12])
+{
+    double mu = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    double tau = 2.0 * sign_of(q[3]) * (1.0 + mu * mu / 6.0);
+    double nu = -2.0 * sign_of(q[3]) * (2.0 / 3.0 + mu * mu / 5.0);
+    for (int i = 0; i < 3; ++i) {
+        D[4 * i] = -2 * q[i];
+        for (int j = 0; j < 3; ++j) D[4 * i + 1 + j] = tau * (i == j) + nu * q[i] * q[j];
+    }
+}
+
+/* dq2q1_by_dq1(q2) (sgn = +1) and dq2q1_by_dq2(q1) (sgn = -1), Transform.cpp:91-105: 4 x 4 */
+static void dq2q1_by(const double q[4], double sgn, double M[16])
+{
+    double S[9];
+    skew(q, S);
+    for (int i = 0; i < 16; ++i) M[i] = 0;
+    for (int j = 0; j < 3; ++j) { M[1 + j] = -q[j]; M[4 * (1 + j)] = q[j]; }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M[4 * (1 + i) + 1 + j] = sgn * S[3 * i + j];
+    for (int i = 0; i < 4; ++i) M[5 * i] += q[3];
+}
+
+/* dr2r1_by_r1 / dr2r1_by_r2, Transform.cpp:107-121 */
+static void dr2r1_by(const double q[4], const double qa[4] /* 4x4 from */, double sgn, const double qb[4] /* dq_by_dr of */, double J[9])
+{
+    double A[12], M[16], B[12], T[12];
+    dr_by_dq(q, A);
+    dq2q1_by(qa, sgn, M);
+    dq_by_dr(qb, B);
+    mat_mul(3, 4, 4, A, M, T);
+    mat_mul(3, 4, 3, T, B, J);
+}
+
+/* drx_by_dr, Transform.cpp:123-137 */
+static void drx_by_dr(const double q[4], const double x[3], double J[9])
+{
+    double r[3];
+    q_to_r(q, r);
+    double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    double alpha = 1.0 - theta * theta / 6.0, beta = 0.5 - theta * theta / 24.0;
+    double gamma = 1.0 / 3.0 - theta * theta / 30.0, delta = -1.0 / 12.0 + theta * theta / 180.0;
+    double Sx[9], Sr[9], A[9], B[9], T1[9], T2[9], T3[9];
+    skew(x, Sx);
+    skew(r, Sr);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            A[3 * i + j] = gamma * r[i] * r[j] - beta * Sr[3 * i + j] + alpha * (i == j);
+            B[3 * i + j] = delta * r[i] * r[j] + 2.0 * beta * (i == j);
+        }
+    mat_mul(3, 3, 3, Sx, A, T1);
+    mat_mul(3, 3, 3, Sr, Sx, T2);
+    mat_mul(3, 3, 3, T2, B, T3);
+    for (int i = 0; i < 9; ++i) J[i] = -T1[i] - T3[i];
+}
+
+/* cov (6x6 column-major) += J C J^T with J given as four row-major 3x3 blocks [[J00, J01], [J10, J11]] */
+static void add_jcjt(const double *J00, const double *J01, const double *J10, const double *J11, const double *C, double *cov)
+{
+    double J[36], T[36];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            J[6 * i + j] = J00[3 * i + j]; J[6 * i + 3 + j] = J01[3 * i + j];
+            J[6 * (3 + i) + j] = J10[3 * i + j]; J[6 * (3 + i) + 3 + j] = J11[3 * i + j];
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0;
+            for (int p = 0; p < 6; ++p) s += J[6 * i + p] * C[p + 6 * j];          /* C column-major */
+            T[6 * i + j] = s;
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0;
+            for (int p = 0; p < 6; ++p) s += T[6 * i + p] * J[6 * j + p];
+            cov[i + 6 * j] += s;
+        }
+}
+
+/* TransformWithUncertainty::operator* (Transform.cpp:215-254): result = t2 * t1.  cov1 / cov2 NULL = that transform
+ * carries no uncertainty (hasUncertainty() false); with both NULL the result has none either (out_cov zeroed). */
+void slko_transform_compose(const double t2[7], const double *cov2, const double t1[7], const double *cov1,
+                            double out_t[7], double out_cov[36])
+{
+    double R1[9], R2[9], R[9], q1[4], q2[4], q[4], Z[9] = {0}, I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    quat_to_rot(t1 + 3, R1);
+    quat_to_rot(t2 + 3, R2);
+    mat_mul(3, 3, 3, R2, R1, R);
+    for (int i = 0; i < 3; ++i) out_t[i] = R2[3 * i] * t1[0] + R2[3 * i + 1] * t1[1] + R2[3 * i + 2] * t1[2] + t2[i];
+    rot_to_quat(R, out_t + 3);
+    for (int i = 0; i < 36; ++i) out_cov[i] = 0;
+    if (!cov1 && !cov2) return;                                                     /* :219-220 */
+    rot_to_quat(R1, q1);                                                            /* :222-225 */
+    rot_to_quat(R2, q2);
+    slko_quat_mul(q2, q1, q);
+    if (cov1) {                                                                     /* :232-239 */
+        double J00[9];
+        dr2r1_by(q, q2, 1.0, q1, J00);
+        add_jcjt(J00, Z, Z, R2, cov1, out_cov);
+    }
+    if (cov2) {                                                                     /* :241-248 */
+        double J00[9], J10[9];
+        dr2r1_by(q, q1, -1.0, q2, J00);
+        drx_by_dr(q2, t1, J10);
+        add_jcjt(J00, Z, J10, I, cov2, out_cov);
+    }
+}
+
+/* DeadReckon::updatePose, Affine3d overload (src/core/DeadReckon.hpp:306-330): composition with uncertainty, or
+ * post = prev * delta with postCov = prevCov + deltaCov.  base::guaranteeSPD(postCov) (:326) returns the repaired
+ * matrix, which the reference discards: no effect. */
+void slko_update_pose_affine(const double prev[7], const double prev_cov[36], const double delta[7], const double delta_cov[36],
+                             int use_tf, double post[7], double post_cov[36])
+{
+    if (use_tf) { slko_transform_compose(prev, prev_cov, delta, delta_cov, post, post_cov); return; }
+    slko_transform_compose(prev, NULL, delta, NULL, post, post_cov);
+    for (int i = 0; i < 36; ++i) post_cov[i] = prev_cov[i] + delta_cov[i];
+}
+
+/* DeadReckon::updatePose, RigidBodyState overload (src/core/DeadReckon.hpp:129-239).
+ *   u       = dt v0[3] w0[3] v1[3] w1[3]           (cartesianVelocities[0] = current, [1] = previous sample)
+ *   velcov  = 6x6 column-major, linear 0-2 / angular 3-5; any NaN entry -> the delta covariances are zero (:165-176)
+ *   pose records: pos[3] quat[4] cov_position[9] cov_orientation[9] (3x3 column-major)          = 25
+ *   post (in/out) = pose record + velocity[3] cov_velocity[9] angular_velocity[3] cov_angular_velocity[9] = 49
+ *   delta (out)   = pose record + velocity[3] angular_velocity[3]                                 = 31 */
+void slko_dead_reckon_pose(const double u[13], const double velcov[36], const double prev[25], double post[49],
+                           double delta[31], int use_tf)
+{
+    const double dt = u[0];
+    double d13[13];
+    slko_dead_reckon_delta(u, d13);                                   /* position, orientation (updateAttitude), velocities */
+    for (int i = 0; i < 7; ++i) delta[i] = d13[i];
+    for (int i = 0; i < 3; ++i) { delta[25 + i] = d13[7 + i]; delta[28 + i] = d13[10 + i]; }
+    int has_nan = 0;
+    for (int i = 0; i < 36; ++i) if (velcov[i] != velcov[i]) has_nan = 1;
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) {
+            delta[7 + i + 3 * j] = has_nan ? 0.0 : velcov[i + 6 * j] * dt * dt;                      /* :171 */
+            delta[16 + i + 3 * j] = has_nan ? 0.0 : velcov[(3 + i) + 6 * (3 + j)] * dt * dt;         /* :172 */
+        }
+    if (use_tf) {                                                     /* :202-215 */
+        double c2[36] = {0}, c1[36] = {0}, t[7], c[36];
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) {                             /* Transform.cpp:294-296: [cov_orientation 0; 0 cov_position] */
+                c2[i + 6 * j] = prev[16 + i + 3 * j]; c2[(3 + i) + 6 * (3 + j)] = prev[7 + i + 3 * j];
+                c1[i + 6 * j] = delta[16 + i + 3 * j]; c1[(3 + i) + 6 * (3 + j)] = delta[7 + i + 3 * j];
+            }
+        slko_transform_compose(prev, c2, delta, c1, t, c);
+        for (int i = 0; i < 7; ++i) post[i] = t[i];
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) {                             /* copyToRigidBodyState, Transform.cpp:314-321 */
+                post[16 + i + 3 * j] = c[i + 6 * j];
+                post[7 + i + 3 * j] = c[(3 + i) + 6 * (3 + j)];
+            }
+    } else {                                                          /* :216-223 */
+        double rp[3], q[4];
+        slko_quat_rotate(prev + 3, delta, rp);
+        for (int i = 0; i < 3; ++i) post[i] += rp[i];
+        for (int i = 0; i < 9; ++i) { post[7 + i] += delta[7 + i]; post[16 + i] += delta[16 + i]; }
+        slko_quat_mul(prev + 3, delta + 3, q);
+        for (int i = 0; i < 4; ++i) post[3 + i] = q[i];
+    }
+    for (int i = 0; i < 3; ++i) { post[25 + i] = u[1 + i]; post[37 + i] = u[4 + i]; }            /* :226-229 */
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) {
+            post[28 + i + 3 * j] = velcov[i + 6 * j];
+            post[40 + i + 3 * j] = velcov[(3 + i) + 6 * (3 + j)];
+        }
+}
+
+/* ====================================================================== */
+/* AdaptiveAttitudeCov::matrix (src/filters/MeasurementModels.hpp:181-286) */
+/* ====================================================================== */
+/* Singular value decomposition of the symmetric positive semi-definite 3x3 Uk (a mean of outer products): the
+ * reference calls Eigen::JacobiSVD<MatrixXd>(Uk, ComputeThinU) -- singular values sorted in decreasing order, U =
+ * left singular vectors.  For a symmetric PSD matrix these are its eigenvalues / eigenvectors; restated as a cyclic
+ * Jacobi eigenvalue iteration (U is used only through u u^T and u^T M u, so column signs do not matter). */
+static void sym3_svd(const double A[9] /* row-major symmetric */, double s[3], double U[9] /* columns = vectors, row-major */)
+{
+    double a[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < 9; ++i) a[i] = A[i];
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double apq = a[3 * p + q];
+                if (apq == 0.0) continue;
+                double theta = (a[3 * q + q] - a[3 * p + p]) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 3; ++k) {                        /* A <- A G */
+                    double akp = a[3 * k + p], akq = a[3 * k + q];
+                    a[3 * k + p] = c * akp - sn * akq;
+                    a[3 * k + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {                        /* A <- G^T A */
+                    double apk = a[3 * p + k], aqk = a[3 * q + k];
+                    a[3 * p + k] = c * apk - sn * aqk;
+                    a[3 * q + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double vkp = V[3 * k + p], vkq = V[3 * k + q];
+                    V[3 * k + p] = c * vkp - sn * vkq;
+                    V[3 * k + q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    int idx[3] = {0, 1, 2};
+    double e[3] = {fabs(a[0]), fabs(a[4]), fabs(a[8])};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2 - i; ++j)
+            if (e[idx[j]] < e[idx[j + 1]]) { int t = idx[j]; idx[j] = idx[j + 1]; idx[j + 1] = t; }
+    for (int c = 0; c < 3; ++c) {
+        s[c] = e[idx[c]];
+        for (int k = 0; k < 3; ++k) U[3 * k + c] = V[3 * k + idx[c]];
+    }
+}
+
+/* One call of AdaptiveAttitudeCov::matrix.  State of the object: hist [m1][9] (row-major 3x3 each, zero-initialised,
+ * :162-165), *r1count (starts at 0, :160), *r2count (constructor argument R2COUNT, :158).
+ * xk [n], Pk [n*n] column-major, z [3], H [3*n] column-major (3 x n), R [9] column-major; Rout [9] column-major. */
+void slko_adaptive_attitude_cov(unsigned m1, unsigned m2, double gamma, double *hist, unsigned *r1count, unsigned *r2count,
+                                int n, const double *xk, const double *Pk, const double *z, const double *H, const double *R,
+                                double *Rout)
+{
+    double res[3], Uk[9] = {0}, fooR[9], s[3], U[9], mu[3], Qstar[9] = {0};
+    for (int i = 0; i < 3; ++i) {                                    /* z - H xk, :195 */
+        double hx = 0;
+        for (int j = 0; j < n; ++j) hx += H[i + 3 * j] * xk[j];
+        res[i] = z[i] - hx;
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) hist[9 * (*r1count) + 3 * i + j] = res[i] * res[j];        /* :195-197 */
+    *r1count = (*r1count + 1) % m1;                                  /* :213 */
+    for (unsigned h = 0; h < m1; ++h)                                /* :215-223 */
+        for (int i = 0; i < 9; ++i) Uk[i] += hist[9 * h + i];
+    for (int i = 0; i < 9; ++i) Uk[i] = Uk[i] / (double)m1;
+    for (int i = 0; i < 3; ++i)                                      /* fooR = H Pk H^T + R, :225 */
+        for (int j = 0; j < 3; ++j) {
+            double sum = 0;
+            for (int a = 0; a < n; ++a) {
+                double hp = 0;
+                for (int b = 0; b < n; ++b) hp += H[i + 3 * b] * Pk[b + n * a];
+                sum += hp * H[j + 3 * a];
+            }
+            fooR[3 * i + j] = sum + R[i + 3 * j];
+        }
+    sym3_svd(Uk, s, U);                                              /* :230-235 */
+    for (int c = 0; c < 3; ++c) {                                    /* mu_c = u_c^T fooR u_c, :237-239 */
+        double sum = 0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) sum += U[3 * i + c] * fooR[3 * i + j] * U[3 * j + c];
+        mu[c] = sum;
+    }
+    double mx = s[0] - mu[0];
+    for (int c = 1; c < 3; ++c) if (s[c] - mu[c] > mx) mx = s[c] - mu[c];
+    int use = 0;
+    if (mx > gamma) { *r2count = 0; use = 1; }                       /* :245-258 */
+    else { *r2count = *r2count + 1; use = *r2count < m2; }           /* :259-275 */
+    if (use)
+        for (int c = 0; c < 3; ++c) {
+            double w = s[c] - mu[c] > 0.0 ? s[c] - mu[c] : 0.0;
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) Qstar[3 * i + j] += w * U[3 * i + c] * U[3 * j + c];
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rout[i + 3 * j] = R[i + 3 * j] + Qstar[3 * i + j];          /* :284 */
+}

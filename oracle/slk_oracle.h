@@ -88,6 +88,20 @@ void slko_update_attitude(double dt, const double w0[3], const double w1[3], dou
 void slko_dead_reckon_delta(const double u[13], double delta[13]);
 void slko_pm_dead_reckon(const double *x, double *y, void *ctx);   /* ctx = double[13] u */
 
+/* TransformWithUncertainty::operator* (src/core/Transform.cpp:215-254, Jacobians :35-137) on pos[3] quat[4] transforms
+ * with 6x6 [r t] covariances (NULL = no uncertainty), the Affine3d and RigidBodyState overloads of
+ * DeadReckon::updatePose (src/core/DeadReckon.hpp:306-330, :129-239) and AdaptiveAttitudeCov::matrix
+ * (src/filters/MeasurementModels.hpp:181-286).  Record layouts: see slk_oracle.c. */
+void slko_transform_compose(const double t2[7], const double *cov2, const double t1[7], const double *cov1,
+                            double out_t[7], double out_cov[36]);
+void slko_update_pose_affine(const double prev[7], const double prev_cov[36], const double delta[7], const double delta_cov[36],
+                             int use_tf, double post[7], double post_cov[36]);
+void slko_dead_reckon_pose(const double u[13], const double velcov[36], const double prev[25], double post[49],
+                           double delta[31], int use_tf);
+void slko_adaptive_attitude_cov(unsigned m1, unsigned m2, double gamma, double *hist, unsigned *r1count, unsigned *r2count,
+                                int n, const double *xk, const double *Pk, const double *z, const double *H, const double *R,
+                                double *Rout);
+
 /* measurement models */
 void slko_mm_vo_relative(const slko_layout *lay, const double *X, int m, double *z, void *ctx); /* UsckfUnitTest.cpp:62-86 */
 /* ctx = double[ (m/2) * 4 ]: per 2-D feature (landmark xyz, pose index); pose 0 = statek, 1.. = clones */

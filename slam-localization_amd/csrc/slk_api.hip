@@ -17,6 +17,7 @@
 #include "slk_kernels.hpp"
 #include "slk_usckf.hpp"
 #include "slk_ekf.hpp"
+#include "slk_pose.hpp"
 
 using namespace slk;
 
@@ -469,6 +470,83 @@ int slk_dead_reckon(slk_filter *f, const double *u, int u_stride, double *delta,
     return SLK_OK;
 }
 
+// stage an input of the pose ops through one of the handle's scratch buffers; out-of-place so that several inputs of
+// one call do not share a buffer
+static int stage_pose_in(slk_filter *f, Stage &s, const double *src, size_t n, int where, const double **out)
+{
+    return stage_in(f, s, src, n, where, out);
+}
+
+int slk_transform_compose(slk_filter *f, const double *t2, const double *cov2, const double *t1, const double *cov1,
+                          double *t_out, double *cov_out, int additive, int where)
+{
+    if (!f || !t2 || !t1 || !t_out) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    const size_t B = (size_t)f->B;
+    const double *d2, *d1, *dc2, *dc1;
+    int rc = stage_pose_in(f, f->st_u, t2, B * 7, where, &d2);
+    if (rc) return rc;
+    rc = stage_pose_in(f, f->st_mp, t1, B * 7, where, &d1);
+    if (rc) return rc;
+    rc = stage_pose_in(f, f->st_X, cov2, B * 36, where, &dc2);
+    if (rc) return rc;
+    rc = stage_pose_in(f, f->st_Z, cov1, B * 36, where, &dc1);
+    if (rc) return rc;
+    double *dt = t_out, *dc = cov_out;
+    if (where == SLK_HOST) {
+        rc = stage_reserve(f, f->st_tmpM, B * 7);
+        if (rc) return rc;
+        rc = stage_reserve(f, f->st_tmpP, B * 36);
+        if (rc) return rc;
+        dt = f->st_tmpM.p;
+        dc = cov_out ? f->st_tmpP.p : nullptr;
+    }
+    hipLaunchKernelGGL(transform_compose_kernel, dim3((f->B + 127) / 128), dim3(128), 0, f->stream, f->B, d2, dc2, d1, dc1, dt, dc,
+                       additive);
+    HIPCHECK(hipGetLastError());
+    if (where == SLK_HOST) {
+        HIPCHECK(hipMemcpyAsync(t_out, dt, B * 7 * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+        if (cov_out) HIPCHECK(hipMemcpyAsync(cov_out, dc, B * 36 * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+        HIPCHECK(hipStreamSynchronize(f->stream));
+    }
+    return SLK_OK;
+}
+
+int slk_dead_reckon_pose(slk_filter *f, const double *u, int u_stride, const double *velcov, int c_stride,
+                         const double *prev, double *post, double *delta, int use_tf, int where)
+{
+    if (!f || !u || !velcov || !prev || !post) return SLK_E_INVALID;
+    if ((u_stride != 0 && u_stride < 13) || (c_stride != 0 && c_stride < 36)) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    const size_t B = (size_t)f->B;
+    const double *du, *dv, *dp;
+    int rc = stage_pose_in(f, f->st_u, u, u_stride ? B * u_stride : 13, where, &du);
+    if (rc) return rc;
+    rc = stage_pose_in(f, f->st_Q, velcov, c_stride ? B * c_stride : 36, where, &dv);
+    if (rc) return rc;
+    rc = stage_pose_in(f, f->st_mp, prev, B * 25, where, &dp);
+    if (rc) return rc;
+    double *dpost = post, *ddelta = delta;
+    if (where == SLK_HOST) {
+        rc = stage_reserve(f, f->st_X, B * 49);
+        if (rc) return rc;
+        rc = stage_reserve(f, f->st_Z, B * 31);
+        if (rc) return rc;
+        dpost = f->st_X.p;
+        ddelta = delta ? f->st_Z.p : nullptr;
+        HIPCHECK(hipMemcpyAsync(dpost, post, B * 49 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    }
+    hipLaunchKernelGGL(dead_reckon_pose_kernel, dim3((f->B + 127) / 128), dim3(128), 0, f->stream, f->B, du, u_stride, dv, c_stride,
+                       dp, dpost, ddelta, use_tf);
+    HIPCHECK(hipGetLastError());
+    if (where == SLK_HOST) {
+        HIPCHECK(hipMemcpyAsync(post, dpost, B * 49 * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+        if (delta) HIPCHECK(hipMemcpyAsync(delta, ddelta, B * 31 * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+        HIPCHECK(hipStreamSynchronize(f->stream));
+    }
+    return SLK_OK;
+}
+
 int slk_predict(slk_filter *f, int model, const double *u, int u_stride, const double *Q, int q_stride, int where)
 {
     if (!f) return SLK_E_INVALID;
@@ -868,6 +946,103 @@ int slk_check_sigma_points(slk_filter *f, double *max_cov_err, double *mean_err,
     HIPCHECK(hipMemcpyAsync(max_cov_err, res, B * sizeof(double), kind, f->stream));
     HIPCHECK(hipMemcpyAsync(mean_err, res + B, B * sizeof(double), kind, f->stream));
     if (where == SLK_HOST) HIPCHECK(hipStreamSynchronize(f->stream));
+    return SLK_OK;
+}
+
+struct slk_adaptive {
+    int B, device;
+    unsigned m1, m2, r1count;
+    double gamma;
+    hipStream_t stream;
+    bool own_stream;
+    double *d_hist = nullptr;
+    unsigned *d_r2 = nullptr;
+    Stage st[6];            // host-input staging: xk, Pk, z, H, R, Rout
+};
+
+static int adaptive_stage(slk_adaptive *a, Stage &s, const double *src, size_t n, int where, const double **out)
+{
+    if (where == SLK_DEVICE) { *out = src; return SLK_OK; }
+    if (s.cap < n) {
+        if (s.p) HIPCHECK(hipFree(s.p));
+        s.p = nullptr; s.cap = 0;
+        HIPCHECK(hipMalloc(&s.p, n * sizeof(double)));
+        s.cap = n;
+    }
+    HIPCHECK(hipMemcpyAsync(s.p, src, n * sizeof(double), hipMemcpyHostToDevice, a->stream));
+    *out = s.p;
+    return SLK_OK;
+}
+
+int slk_adaptive_create(int batch, int device, unsigned m1, unsigned m2, double gamma, unsigned r2count, void *stream,
+                        slk_adaptive **out)
+{
+    if (!out || batch < 1 || m1 < 1) return SLK_E_INVALID;
+    int ndev = slk_device_count();
+    if (ndev <= 0) { g_err = "no HIP device: the slk library has no CPU fallback"; return SLK_E_NO_DEVICE; }
+    if (device < 0 || device >= ndev) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(device));
+    slk_adaptive *a = new slk_adaptive();
+    a->B = batch; a->device = device; a->m1 = m1; a->m2 = m2; a->gamma = gamma; a->r1count = 0;   // :158-160
+    a->own_stream = stream == nullptr;
+    if (a->own_stream) {
+        if (hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking) != hipSuccess) { delete a; return SLK_E_HIP; }
+    } else a->stream = (hipStream_t)stream;
+    std::vector<unsigned> r2((size_t)batch, r2count);
+    bool ok = hipMalloc(&a->d_hist, (size_t)batch * m1 * 9 * sizeof(double)) == hipSuccess
+           && hipMalloc(&a->d_r2, (size_t)batch * sizeof(unsigned)) == hipSuccess
+           && hipMemsetAsync(a->d_hist, 0, (size_t)batch * m1 * 9 * sizeof(double), a->stream) == hipSuccess      // :162-165
+           && hipMemcpyAsync(a->d_r2, r2.data(), (size_t)batch * sizeof(unsigned), hipMemcpyHostToDevice, a->stream) == hipSuccess
+           && hipStreamSynchronize(a->stream) == hipSuccess;
+    if (!ok) { g_err = "device allocation failed"; slk_adaptive_destroy(a); return SLK_E_NOMEM; }
+    *out = a;
+    return SLK_OK;
+}
+
+void slk_adaptive_destroy(slk_adaptive *a)
+{
+    if (!a) return;
+    (void)hipSetDevice(a->device);
+    (void)hipStreamSynchronize(a->stream);
+    for (Stage &s : a->st) if (s.p) (void)hipFree(s.p);
+    if (a->d_hist) (void)hipFree(a->d_hist);
+    if (a->d_r2) (void)hipFree(a->d_r2);
+    if (a->own_stream) (void)hipStreamDestroy(a->stream);
+    delete a;
+}
+
+int slk_adaptive_matrix(slk_adaptive *a, int n, const double *xk, const double *Pk, const double *z, const double *H,
+                        const double *R, int r_stride, double *Rout, int where)
+{
+    if (!a || n < 1 || !xk || !Pk || !z || !H || !R || !Rout) return SLK_E_INVALID;
+    if (r_stride != 0 && r_stride < 9) return SLK_E_INVALID;
+    HIPCHECK(hipSetDevice(a->device));
+    const size_t B = (size_t)a->B;
+    const double *dx, *dP, *dz, *dH, *dR;
+    int rc = adaptive_stage(a, a->st[0], xk, B * n, where, &dx); if (rc) return rc;
+    rc = adaptive_stage(a, a->st[1], Pk, B * n * n, where, &dP); if (rc) return rc;
+    rc = adaptive_stage(a, a->st[2], z, B * 3, where, &dz); if (rc) return rc;
+    rc = adaptive_stage(a, a->st[3], H, B * 3 * n, where, &dH); if (rc) return rc;
+    rc = adaptive_stage(a, a->st[4], R, r_stride ? B * r_stride : 9, where, &dR); if (rc) return rc;
+    double *dout = Rout;
+    if (where == SLK_HOST) {
+        Stage &s = a->st[5];
+        if (s.cap < B * 9) {
+            if (s.p) HIPCHECK(hipFree(s.p));
+            s.p = nullptr; s.cap = 0;
+            HIPCHECK(hipMalloc(&s.p, B * 9 * sizeof(double)));
+            s.cap = B * 9;
+        }
+        dout = s.p;
+    }
+    hipLaunchKernelGGL(adaptive_attitude_cov_kernel, dim3((a->B + 127) / 128), dim3(128), 0, a->stream, a->B, a->m1, a->m2, a->gamma,
+                       a->d_hist, a->r1count, a->d_r2, n, dx, dP, dz, dH, dR, r_stride, dout);
+    HIPCHECK(hipGetLastError());
+    a->r1count = (a->r1count + 1) % a->m1;                                           // :213
+    if (where == SLK_HOST) {
+        HIPCHECK(hipMemcpyAsync(Rout, dout, B * 9 * sizeof(double), hipMemcpyDeviceToHost, a->stream));
+        HIPCHECK(hipStreamSynchronize(a->stream));
+    }
     return SLK_OK;
 }
 

@@ -31,7 +31,8 @@ EXPORTS = [
     "slk_update_from_sigma", "slk_usckf_cloning", "slk_usckf_set_measurement", "slk_msckf_resize",
     "slk_get_outliers", "slk_get_status", "slk_clear_status", "slk_sync", "slk_timer_start", "slk_timer_stop",
     "slk_selftest_mfma", "slk_set_rebuild_precision", "slk_dead_reckon", "slk_msckf_clone_pose", "slk_msckf_drop_clone", "slk_update_ekf",
-    "slk_check_sigma_points", "slk_update_innovation", "slk_update_selected",
+    "slk_check_sigma_points", "slk_update_innovation", "slk_update_selected", "slk_transform_compose",
+    "slk_dead_reckon_pose", "slk_adaptive_create", "slk_adaptive_destroy", "slk_adaptive_matrix",
 ]
 
 
@@ -89,6 +90,14 @@ def load_library(path=None):
     lib.slk_selftest_mfma.argtypes = [ip]
     lib.slk_set_rebuild_precision.argtypes = [vp, ip]
     lib.slk_check_sigma_points.argtypes = [vp, vp, vp, ip]
+    lib.slk_update_innovation.argtypes = [vp, ip, vp, ip, vp, vp, ip, vp, ip, vp, ip]
+    lib.slk_update_selected.argtypes = [vp, ip, vp, ip, vp, vp, ip, vp, ip, vp, ip]
+    lib.slk_transform_compose.argtypes = [vp, vp, vp, vp, vp, vp, vp, ip, ip]
+    lib.slk_dead_reckon_pose.argtypes = [vp, vp, ip, vp, ip, vp, vp, vp, ip, ip]
+    lib.slk_adaptive_create.argtypes = [ip, ip, C.c_uint, C.c_uint, C.c_double, C.c_uint, vp, C.POINTER(vp)]
+    lib.slk_adaptive_destroy.argtypes = [vp]
+    lib.slk_adaptive_destroy.restype = None
+    lib.slk_adaptive_matrix.argtypes = [vp, ip, vp, vp, vp, vp, vp, ip, vp, ip]
     if path is None:
         _lib = lib
     return lib
@@ -313,6 +322,43 @@ class _FilterBatch:
         _check(self._lib.slk_dead_reckon(self._h, ua.ptr, ua.stride, out.ctypes.data, HOST), "slk_dead_reckon")
         return out
 
+    def transform_compose(self, t2, cov2, t1, cov1, additive=False):
+        """TransformWithUncertainty::operator* (src/core/Transform.cpp:215-254) for the batch: t [B, 7] = pos quat,
+        cov [B, 6, 6] in [r t] order or None (no uncertainty) -> (t [B, 7], cov [B, 6, 6]).  additive=True is the other
+        branch of DeadReckon::updatePose's Affine3d overload (src/core/DeadReckon.hpp:317-323)."""
+        B = self.B
+
+        def cm(c):
+            if c is None:
+                return None
+            return np.ascontiguousarray(np.transpose(np.broadcast_to(np.asarray(c, dtype=np.float64), (B, 6, 6)), (0, 2, 1)))
+        a2 = np.ascontiguousarray(np.broadcast_to(np.asarray(t2, dtype=np.float64), (B, 7)))
+        a1 = np.ascontiguousarray(np.broadcast_to(np.asarray(t1, dtype=np.float64), (B, 7)))
+        c2, c1 = cm(cov2), cm(cov1)
+        to, co = np.empty((B, 7)), np.empty((B, 6, 6))
+        _check(self._lib.slk_transform_compose(self._h, a2.ctypes.data, c2.ctypes.data if c2 is not None else None,
+                                               a1.ctypes.data, c1.ctypes.data if c1 is not None else None,
+                                               to.ctypes.data, co.ctypes.data, int(bool(additive)), HOST), "slk_transform_compose")
+        return to, np.ascontiguousarray(np.transpose(co, (0, 2, 1)))
+
+    def dead_reckon_pose(self, u, velcov, prev, post, use_tf=False):
+        """DeadReckon::updatePose, RigidBodyState overload (src/core/DeadReckon.hpp:129-239) for the batch.  Records as in
+        include/slk.h: prev [B, 25], post [B, 49] (accumulated into without use_tf), -> (post [B, 49], delta [B, 31]);
+        velcov [6, 6] shared or [B, 6, 6]."""
+        B = self.B
+        ua = _rows(u, B, 13)
+        vc = np.asarray(velcov, dtype=np.float64)
+        if vc.ndim == 2:
+            vca, cs = np.ascontiguousarray(vc.T), 0
+        else:
+            vca, cs = np.ascontiguousarray(np.transpose(vc, (0, 2, 1))), 36
+        pv = np.ascontiguousarray(np.broadcast_to(np.asarray(prev, dtype=np.float64), (B, 25)))
+        po = np.array(np.broadcast_to(np.asarray(post, dtype=np.float64), (B, 49)), dtype=np.float64, order="C")
+        de = np.empty((B, 31))
+        _check(self._lib.slk_dead_reckon_pose(self._h, ua.ptr, ua.stride, vca.ctypes.data, cs, pv.ctypes.data, po.ctypes.data,
+                                              de.ctypes.data, int(bool(use_tf)), HOST), "slk_dead_reckon_pose")
+        return po, de
+
     def predict_functor(self, f, Q):
         """predict(f, Q) with an arbitrary Python callable f: state[13] -> state[13], applied on the host."""
         X = self.predict_sigma_points()
@@ -443,3 +489,39 @@ class Usckf(_FilterBatch):
     def PkSingleState(self, which=STATEK_I):                 # Usckf.hpp:493-516
         o = {STATEK: 0, STATEK_L: 12, STATEK_I: 24}.get(which, 24)
         return self._getP()[:, o:o + 12, o:o + 12]
+
+
+class AdaptiveAttitudeCov:
+    """Batch of B independent localization::AdaptiveAttitudeCov objects (src/filters/MeasurementModels.hpp:136-286)
+    resident on the device; matrix() is one call of the reference's ::matrix per object and returns the adapted
+    measurement noise [B, 3, 3] -- the R of update()."""
+
+    def __init__(self, batch, m1, m2, gamma, r2count, device=0, stream=None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        _check(self._lib.slk_adaptive_create(batch, device, m1, m2, gamma, r2count, stream, C.byref(self._h)), "slk_adaptive_create")
+        self.B = batch
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.slk_adaptive_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def matrix(self, xk, Pk, z, H, R):
+        B = self.B
+        x = np.ascontiguousarray(np.asarray(xk, dtype=np.float64).reshape(B, -1))
+        n = x.shape[1]
+        P = np.ascontiguousarray(np.transpose(np.asarray(Pk, dtype=np.float64).reshape(B, n, n), (0, 2, 1)))
+        zz = np.ascontiguousarray(np.asarray(z, dtype=np.float64).reshape(B, 3))
+        Hc = np.ascontiguousarray(np.transpose(np.asarray(H, dtype=np.float64).reshape(B, 3, n), (0, 2, 1)))
+        ra = _mat(np.asarray(R), B, 3)
+        out = np.empty((B, 3, 3))
+        _check(self._lib.slk_adaptive_matrix(self._h, n, x.ctypes.data, P.ctypes.data, zz.ctypes.data, Hc.ctypes.data, ra.ptr,
+                                             ra.stride, out.ctypes.data, HOST), "slk_adaptive_matrix")
+        return np.ascontiguousarray(np.transpose(out, (0, 2, 1)))

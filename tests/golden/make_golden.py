@@ -184,6 +184,47 @@ def msckf_ekf():
     np.savez(os.path.join(OUT, "msckf_ekf.npz"), **out)
 
 
+def pose_ops():
+    """SURVEY 8f-3 / 8f-4: TransformWithUncertainty::operator* (Transform.cpp:215-254), both overloads of
+    DeadReckon::updatePose (DeadReckon.hpp:129-239, :306-330) and AdaptiveAttitudeCov::matrix
+    (MeasurementModels.hpp:181-286): oracle output, written once the numpy twin agrees (quaternions up to sign)."""
+    s = sc.synthetic_pose_ops()
+    B = s["B"]
+
+    def same_transform(a, b):
+        return max(np.abs(a[:3] - b[:3]).max(), min(np.abs(a[3:] - b[3:]).max(), np.abs(a[3:] + b[3:]).max()))
+    out = {}
+    for name, use2, use1 in (("both", True, True), ("first", True, False), ("second", False, True), ("none", False, False)):
+        T, Cv = [], []
+        for b in range(B):
+            c2 = s["cov2"][b] if use2 else None
+            c1 = s["cov1"][b] if use1 else None
+            t, c = o.transform_compose(s["t2"][b], c2, s["t1"][b], c1)
+            tn, cn = npc.transform_compose(s["t2"][b], c2, s["t1"][b], c1)
+            assert same_transform(t, tn) <= TOL and np.abs(c - cn).max() <= TOL * max(1.0, np.abs(cn).max()), (name, b)
+            T.append(t); Cv.append(c)
+        out[f"compose_{name}_t"], out[f"compose_{name}_cov"] = np.array(T), np.array(Cv)
+    for tf in (0, 1):
+        P, D = [], []
+        for b in range(B):
+            post = np.r_[s["prev"][b], np.zeros(24)]
+            po, de = o.dead_reckon_pose(s["u"][b], s["velcov"], s["prev"][b], post, tf)
+            pn, dn = npc.dead_reckon_pose(s["u"][b], s["velcov"], s["prev"][b], post, tf)
+            assert same_transform(po[:7], pn[:7]) <= TOL and np.abs(po[7:] - pn[7:]).max() <= TOL and np.abs(de - dn).max() <= TOL
+            P.append(po); D.append(de)
+        out[f"dr_pose_tf{tf}_post"], out[f"dr_pose_tf{tf}_delta"] = np.array(P), np.array(D)
+    objs = [o.AdaptiveAttitudeCov(s["m1"], s["m2"], s["gamma"], s["r2count"]) for _ in range(B)]
+    twin = [npc.AdaptiveAttitudeCov(s["m1"], s["m2"], s["gamma"], s["r2count"]) for _ in range(B)]
+    Rs = np.zeros((s["steps"], B, 3, 3))
+    for k in range(s["steps"]):
+        for b in range(B):
+            Rs[k, b] = objs[b].matrix(s["xk"][k, b], s["Pk"][b], s["z"][k, b], s["H"][k, b], s["R"])
+            Rn = twin[b].matrix(s["xk"][k, b], s["Pk"][b], s["z"][k, b], s["H"][k, b], s["R"])
+            assert rel(Rs[k, b], Rn) <= 1e-11 and objs[b].r2.value == twin[b].r2count, (k, b)
+    out["adaptive_R"] = Rs
+    np.savez(os.path.join(OUT, "pose_ops.npz"), **out)
+
+
 if __name__ == "__main__":
     msckf_ekf()
     dead_reckon()
@@ -191,6 +232,7 @@ if __name__ == "__main__":
     usckf_spd()
     msckf_unit_test()
     msckf_batch()
+    pose_ops()
     for fn in sorted(os.listdir(OUT)):
         if fn.endswith(".npz"):
             print(fn, os.path.getsize(os.path.join(OUT, fn)))

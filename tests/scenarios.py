@@ -176,3 +176,31 @@ def synthetic_ekf(B, k, m, seed=0xEC0F, outliers=True):
             for r in rng.choice(m // 2, size=1 + b % 3, replace=False):
                 z[b, 2 * r] += 25.0
     return dict(B=B, k=k, m=m, N=N, Nq=s["Nq"], mean=s["mean"], P=s["P"].reshape(B, N, N), H=H, R=R, z=z, zmean=zmean)
+
+
+def synthetic_pose_ops(B=24, seed=0xD0E5):
+    """Inputs of the pose-with-uncertainty ops: transform pairs with 6x6 [r t] covariances, dead
+    reckoning samples with a velocity covariance, and an AdaptiveAttitudeCov measurement sequence.  Rotations stay below
+    ~100 degrees, where Eigen's rotation-matrix -> quaternion conversion takes its trace > 0 branch (w > 0)."""
+    rng = np.random.default_rng(seed)
+
+    def spd(n, s, count):
+        A = rng.normal(0, s, (count, n, n))
+        return A @ np.transpose(A, (0, 2, 1)) + 1e-4 * np.eye(n)
+    t2 = np.concatenate([rng.normal(0, 2, (B, 3)), quat_exp(rng.normal(0, 0.5, (B, 3)))], axis=1)
+    t1 = np.concatenate([rng.normal(0, 1, (B, 3)), quat_exp(rng.normal(0, 0.4, (B, 3)))], axis=1)
+    u = np.concatenate([0.01 + 0.1 * rng.random((B, 1)), rng.normal(0, 1, (B, 3)), rng.normal(0, 0.5, (B, 3)),
+                        rng.normal(0, 1, (B, 3)), rng.normal(0, 0.5, (B, 3))], axis=1)
+    prev = np.concatenate([rng.normal(0, 3, (B, 3)), quat_exp(rng.normal(0, 0.5, (B, 3))),
+                           np.transpose(spd(3, 0.1, B), (0, 2, 1)).reshape(B, 9),
+                           np.transpose(spd(3, 0.05, B), (0, 2, 1)).reshape(B, 9)], axis=1)
+    n, steps = 12, 30
+    H = np.zeros((steps, B, 3, n))
+    H[:, :, :, 3:6] = np.eye(3)
+    H += rng.normal(0, 0.01, H.shape)
+    xk = rng.normal(0, 0.1, (steps, B, n))
+    noise = np.where((np.arange(steps) % 7 == 0)[:, None, None], 0.3, 0.03)
+    z = np.einsum("sbij,sbj->sbi", H, xk) + rng.normal(0, 1, (steps, B, 3)) * noise
+    return dict(B=B, t2=t2, t1=t1, cov2=spd(6, 0.05, B), cov1=spd(6, 0.03, B), u=u, velcov=spd(6, 0.1, 1)[0], prev=prev,
+                n=n, steps=steps, xk=xk, Pk=spd(n, 0.02, B), z=z, H=H, R=spd(3, 0.02, 1)[0],
+                m1=5, m2=3, gamma=0.002, r2count=0)
