@@ -209,7 +209,7 @@ static int ensure_dynamic_lds(const void *kern, int device, size_t lds)
 }
 
 // ---------------------------------------------------------------------------- launch helpers
-template <int NT, int NTHREADS>
+template <int NT, int NTHREADS, int KST = -1, int MST = 0>
 static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
 {
     KArgs a = a0;
@@ -236,7 +236,7 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
     }
     size_t lds = (size_t)cv.total * sizeof(double);
     if (lds > 160 * 1024) { g_err = "state too large for the LDS-resident kernel"; return SLK_E_UNSUPPORTED; }
-    auto kern = msckf_step_kernel<NT, NTHREADS>;
+    auto kern = msckf_step_kernel<NT, NTHREADS, KST, MST>;
     int rc_lds = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), f->cfg.device, lds);
     if (rc_lds) return rc_lds;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(NTHREADS), lds, f->stream, a);
@@ -244,14 +244,28 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
     return SLK_OK;
 }
 
+// Exact-shape instantiations of the headline workload (BASELINE.json configs[2] / [3]: k = 8 clones, N = 60; with
+// m = 8 measurement rows every LDS offset is a compile-time constant too); every other shape runs the same kernel
+// source with run-time sizes.
+static int launch_msckf_n60(slk_filter *f, const KArgs &a)
+{
+    if (a.lay.k == 8 && a.m == 8 && a.do_update && a.emit == 0 && a.rebuild_prec == 0) return launch_msckf_inst<4, 256, 8, 8>(f, a);
+    if (a.lay.k == 8) return launch_msckf_inst<4, 256, 8>(f, a);
+    return launch_msckf_inst<4, 256>(f, a);
+}
+
 static int launch_msckf(slk_filter *f, const KArgs &a)
 {
     int NT = (a.lay.N + 15) / 16;
+#ifdef SLK_DEV_N60      // development builds (tools/ab.sh): only the headline instantiations, for quick A/B turnarounds
+    if (NT == 4) return launch_msckf_n60(f, a);
+    g_err = "development build: N = 49..64 only"; return SLK_E_UNSUPPORTED;
+#else
     switch (NT) {
     case 1: return launch_msckf_inst<1, 64>(f, a);
     case 2: return launch_msckf_inst<2, 64>(f, a);
     case 3: return launch_msckf_inst<3, 256>(f, a);
-    case 4: return launch_msckf_inst<4, 256>(f, a);
+    case 4: return launch_msckf_n60(f, a);
     case 5: return launch_msckf_inst<5, 256>(f, a);
     case 6: return launch_msckf_inst<6, 256>(f, a);
     case 7: case 8: return launch_msckf_inst<8, 256>(f, a);
@@ -259,6 +273,7 @@ static int launch_msckf(slk_filter *f, const KArgs &a)
     case 11: case 12: case 13: return launch_msckf_inst<13, 512>(f, a);
     default: g_err = "state dimension above 208 is not supported by this build"; return SLK_E_UNSUPPORTED;
     }
+#endif
 }
 
 template <int NT>
@@ -278,6 +293,10 @@ static int launch_usckf_inst(slk_filter *f, const KArgs &a)
 static int launch_usckf(slk_filter *f, const KArgs &a)
 {
     int NT = (a.lay.N + 15) / 16;
+#ifdef SLK_DEV_N60
+    (void)NT; (void)f; (void)a;
+    g_err = "development build: Msckf only"; return SLK_E_UNSUPPORTED;
+#else
     switch (NT) {
     case 3: return launch_usckf_inst<3>(f, a);
     case 4: return launch_usckf_inst<4>(f, a);
@@ -285,6 +304,7 @@ static int launch_usckf(slk_filter *f, const KArgs &a)
     case 6: return launch_usckf_inst<6>(f, a);
     default: g_err = "Usckf state dimension above 96 is not supported by this build"; return SLK_E_UNSUPPORTED;
     }
+#endif
 }
 
 #ifdef SLK_STAMPS
@@ -598,6 +618,9 @@ int slk_update_ekf(slk_filter *f, const double *z, const double *zmean, const do
 #ifdef SLK_STAMPS
     a.dbg = g_dbg;
 #endif
+#ifdef SLK_DEV_N60
+    g_err = "development build: no EKF kernels"; return SLK_E_UNSUPPORTED;
+#else
     const size_t lds = ekf_lds_doubles(N, m) * sizeof(double);
     if (m <= 128 && N <= 64 && lds <= 140 * 1024) {               // factorisations, QR and thinQ resident in LDS
         auto kern = msckf_ekf_lds_kernel<1024>;
@@ -609,6 +632,7 @@ int slk_update_ekf(slk_filter *f, const double *z, const double *zmean, const do
     }
     HIPCHECK(hipGetLastError());
     return SLK_OK;
+#endif
 }
 
 int slk_step(slk_filter *f, int pmodel, const double *u, int u_stride, const double *Q, int q_stride,

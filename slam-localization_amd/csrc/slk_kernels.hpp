@@ -109,7 +109,22 @@ __host__ __device__ __forceinline__ int rot_count(const Lay &L, int b)
 
 // ------------------------------------------------------------------ packed lower-triangular factor
 // column j holds rows j..n-1 contiguously: element (i, j), i >= j, at j*(2n - j + 1)/2 + (i - j)
-__host__ __device__ __forceinline__ int pk(int n, int i, int j) { return ((j * (2 * n - j + 1)) >> 1) + (i - j); }
+// (device: 24-bit multiply -- full rate, the indices stay far below 2^23 -- instead of the quarter-rate 32-bit one)
+__host__ __device__ __forceinline__ int pkcol(int n, int j)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (__mul24(j, 2 * n - j + 1) >> 1) - j;
+#else
+    return ((j * (2 * n - j + 1)) >> 1) - j;
+#endif
+}
+__host__ __device__ __forceinline__ int pk(int n, int i, int j) { return pkcol(n, j) + i; }
+// column base of the packed factor for column k0 + g (g = lane >> 4, tri_g = g (g + 1) / 2): pk(n, t, k0 + g) = that + t
+__device__ __forceinline__ int packed_colbase(int n, int k0, int g, int tri_g)
+{
+    return ((k0 * (2 * n - k0 - 1)) >> 1) + __mul24(g, n - k0) - tri_g;
+}
+
 __host__ __device__ __forceinline__ int pk_size(int n) { return n * (n + 1) / 2; }
 __device__ __forceinline__ double Lz(const double *Lp, int n, int t, int j)
 {
@@ -122,7 +137,7 @@ __device__ __forceinline__ double Lz(const double *Lp, int n, int t, int j)
 
 // ------------------------------------------------------------------ LDS carve (in doubles)
 struct Carve {
-    int Lp, mu, ref, delta, md, pn12, small, colbuf, pool, total;
+    int Lp, mu, ref, delta, md, cq, pn12, small, colbuf, pool, total;
     int S, LDD, TN, W;   // W = rotation-row items that differ from X_0 (sum over blocks of rot_count)
 };
 
@@ -143,6 +158,7 @@ __host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT, bool bi
     c.ref = o;    o += round_up(Nq, 2);
     c.delta = o;  o += round_up(N, 2);
     c.md = o;     o += round_up(N, 2);
+    c.cq = o;     o += 4 * L.nso3;                 // ref_b^-1 * mu_b per SO(3) block (mean loop)
     c.pn12 = o;   o += 144;
     c.small = o;  o += 96;
     c.colbuf = o; o += big ? (4 * 34 + 136) : 4 * ((c.TN > 32 ? c.TN : 32) + 2);   // big: cholm<1..2> buffer + packed 16x16 factor
@@ -209,7 +225,7 @@ __device__ __forceinline__ void msckf_rot_item(int w, int &b, int &i)
 // The (block, sigma point) -> addresses / signs arithmetic depends on the layout only: the host tabulates it
 // once per handle (rot_item_descriptor), the kernels unpack one 64-bit word per item.
 //   bits 0-15 index of L(toff+2, j) in the packed factor, 16 / 17 "j <= toff" / "j <= toff+1",
-//   18-19 sign (0: X_0, 1: +L_j, 2: -L_j), 20-27 toff, 28-37 soff
+//   18-19 sign (0: X_0, 1: +L_j, 2: -L_j), 20-27 toff, 28-37 soff, 38-43 SO(3) block
 __host__ __device__ inline unsigned long long rot_item_descriptor(int N, int w)
 {
     int b = 0;
@@ -219,21 +235,23 @@ __host__ __device__ inline unsigned long long rot_item_descriptor(int N, int w)
     const unsigned long long a2 = (unsigned long long)(pk(N, to + 2, j));
     const unsigned long long sc = (i == 0) ? 0 : ((i & 1) ? 1 : 2);
     return a2 | ((unsigned long long)(j <= to) << 16) | ((unsigned long long)(j <= to + 1) << 17) | (sc << 18)
-           | ((unsigned long long)to << 20) | ((unsigned long long)so << 28);
+           | ((unsigned long long)to << 20) | ((unsigned long long)so << 28) | ((unsigned long long)b << 38);
 }
-__device__ __forceinline__ void rot_deviation_desc(unsigned long long d, const double *mu, const double *ref, const double *Lp,
+// cq[4 b] = ref_b^-1 * mu_b per SO(3) block (kept current by whoever moves the reference): (mu_b exp(v)) [-] ref_b =
+// log(ref_b^-1 mu_b exp(v)) = log(cq_b exp(v)) -- one quaternion product per item instead of two
+__device__ __forceinline__ void rot_deviation_desc(unsigned long long d, const double *cq, const double *Lp,
                                                    const double *delta, double &dx, double &dy, double &dz)
 {
     const unsigned lo = (unsigned)d;
-    const int a2 = lo & 0xffff, to = (lo >> 20) & 0xff, so = (int)((d >> 28) & 0x3ff);
+    const int a2 = lo & 0xffff, to = (lo >> 20) & 0xff, b = (int)((d >> 38) & 0x3f);
     const bool in0 = lo & (1u << 16), in1 = lo & (1u << 17);
     const unsigned sc = (lo >> 18) & 3;
     const double sgn = (sc == 1) ? 1.0 : ((sc == 2) ? -1.0 : 0.0);
     const double l0 = Lp[in0 ? a2 - 2 : 0], l1 = Lp[in1 ? a2 - 1 : 0], l2 = Lp[a2];
     const double d0 = delta[to], d1 = delta[to + 1], d2 = delta[to + 2];
-    const Quat qm = ldq(mu + so), qr = ldq(ref + so);
+    const Quat c = ldq(cq + 4 * b);
     const double v0 = d0 + sgn * (in0 ? l0 : 0.0), v1 = d1 + sgn * (in1 ? l1 : 0.0), v2 = d2 + sgn * l2;
-    so3_boxminus(qmul(qm, so3_exp(v0, v1, v2)), qr, dx, dy, dz);
+    so3_log(qmul(c, so3_exp(v0, v1, v2)), dx, dy, dz);
 }
 // (mu [+] (delta +- L_j))_b [-] ref_b for item (b, i): all operands loaded up front (clamped addresses,
 // selects afterwards) so the LDS round trips overlap; an item exists only for j <= toff + 2
@@ -243,7 +261,7 @@ __device__ __forceinline__ void rot_deviation(const double *mu, const double *re
     const int to = msckf_toff(b), so = msckf_soff(b);
     const int j = (i > 0) ? ((i - 1) >> 1) : 0;
     const double sgn = (i == 0) ? 0.0 : ((i & 1) ? 1.0 : -1.0);
-    const int jb = ((j * (2 * N - j + 1)) >> 1) - j;                  // pk(N, t, j) = jb + t
+    const int jb = pkcol(N, j);                                       // pk(N, t, j) = jb + t
     const bool in0 = j <= to, in1 = j <= to + 1;
     const double l0 = Lp[in0 ? jb + to : 0], l1 = Lp[in1 ? jb + to + 1 : 0], l2 = Lp[jb + to + 2];
     const double d0 = delta[to], d1 = delta[to + 1], d2 = delta[to + 2];
@@ -563,7 +581,7 @@ __device__ __forceinline__ int cholw_factor(d4 (&acc)[NT], double *Lp, int n, do
                                             int wave, int *flag)
 {
     constexpr int LDC = CholM<NT>::LDC;
-    const int c = lane & 15, g = lane >> 4;
+    const int c = lane & 15, g = lane >> 4, tri_g = (g * (g + 1)) >> 1;
     int fail = -1;
     if (wave == 0 && lane == 0) *flag = 0x7fffffff;      // ordered before the atomicMin at the end by the step barriers
 #pragma unroll
@@ -629,18 +647,19 @@ __device__ __forceinline__ int cholw_factor(d4 (&acc)[NT], double *Lp, int n, do
                     if (rho == kap) f = sg;
                     if (rho < kap) f = 0.0;               // strictly upper part of the pivot block
                     frag = f;
-                    if (rho >= kap && rho < n && kap < n) Lp[pk(n, rho, kap)] = f;
+                    if (rho >= kap && rho < n && kap < n) Lp[packed_colbase(n, k0, g, tri_g) + rho] = f;
                 }
                 __syncthreads();
                 if (part) {
                     // 4. rank-4 update of this wave's tiles; fragments of the tile rows above come from the factor
                     const int kap = k0 + g;
+                    const int cb = packed_colbase(n, k0, g, tri_g) + c;      // one column base per step, tile rows by offset
                     double fj[NT];
 #pragma unroll
                     for (int J = JK; J < NT; ++J) {
                         const int rho = 16 * J + c;
                         const bool in = J < wave && rho >= kap && rho < n && kap < n;
-                        const double lv = Lp[in ? pk(n, rho, kap) : 0];
+                        const double lv = Lp[in ? cb + 16 * J : 0];
                         fj[J] = (J == wave) ? frag : (in ? lv : 0.0);
                     }
 #pragma unroll
@@ -736,6 +755,188 @@ __device__ __forceinline__ int chol_blocked_mem(double *Lp, int n, double *panel
     return fail;
 }
 
+// ------------------------------------------------------------------ covariance downdate as a factor update
+// applyDelta's Cholesky (Msckf.hpp:262-263 -> :659-662) factors Pk - K S K^T.  With Pk = L L^T, covXZ = L A
+// (A = 1/2 (Z_{2j+1} - Z_{2j+2})_j, exact while no rotation column wraps) and S = Ls Ls^T:
+//     Pk - K S K^T = L (I - B B^T) L^T,   B = A Ls^-T   (N x m', m' <= 8 surviving rows),
+// so the new factor is L' = L M with M = chol(I - B B^T): lower triangular, positive diagonal -- the same unique
+// factor Eigen::LLT would return for the downdated matrix, up to rounding.  M is identity plus rank m' structure:
+//     M_jj = sqrt(d_j),  M_ij = b_i . w_j (i > j),
+//     G_j = I - sum_{k<j} b_k b_k^T  (8 x 8),  q_j = G_j^-1 b_j,  d_j = 1 - b_j . q_j,  w_j = -q_j / sqrt(d_j)
+// (Schur complements of I - B B^T through the Woodbury identity).  The G_j are PREFIX sums over the rows of B: one
+// wave scans them across its lanes (lane j = column j) and every lane factors its own 8 x 8 matrix -- no N-step serial
+// chain, no workgroup barrier -- and L M is a triangular matrix product on the matrix cores.
+
+// DPP moves of a double (two dwords); invalid source lanes read 0.0 (bound_ctrl)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_f64(double x)
+{
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    const int h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(h2, l2);
+}
+// inclusive prefix sum over the 64 lanes of a wave (rows of 16 with row_shr, then row_bcast 15 / 31)
+__device__ __forceinline__ double wave_inclusive_scan(double x)
+{
+    x += dpp_mov_f64<0x111, 0xf>(x);     // row_shr:1
+    x += dpp_mov_f64<0x112, 0xf>(x);     // row_shr:2
+    x += dpp_mov_f64<0x114, 0xf>(x);     // row_shr:4
+    x += dpp_mov_f64<0x118, 0xf>(x);     // row_shr:8
+    x += dpp_mov_f64<0x142, 0xa>(x);     // row_bcast:15 into rows 1 and 3
+    x += dpp_mov_f64<0x143, 0xc>(x);     // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
+// B / W buffers: 64 rows x 8 columns, column pairs interleaved so that the two 16-lane halves of an MFMA operand read
+// (column 4s + g, g = 0 / 1) fall into one contiguous 32-double span: element (row, c) at (c >> 1) * 128 + 2 * row + (c & 1)
+__device__ __forceinline__ int bw_idx(int row, int c) { return (c >> 1) * 128 + 2 * row + (c & 1); }
+constexpr int BW_SIZE = 512;
+
+// One wave: lane j holds row j of B (zeros for j >= N and for columns >= m').  Writes Bbuf, Wbuf, mdiag[j] = sqrt(d_j).
+// Returns false if I - B B^T is not positive definite (uniform over the wave).
+__device__ __forceinline__ bool ldm_columns(const double (&b)[8], int lane, int N, double *Bbuf, double *Wbuf, double *mdiag)
+{
+    const bool live = lane < N;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) Bbuf[bw_idx(lane, c)] = live ? b[c] : 0.0;
+    // G_j = I - sum_{k<j} b_k b_k^T (lower triangle): inclusive scan minus the lane's own term
+    // Packed lower triangle: entry (r, c) at r (r + 1) / 2 + c.  (Running the six scan steps over all 36 entries at a
+    // time instead of entry by entry measured 0.5 % slower: more live registers.)
+#define SLK_G(r, c) Gf[(r) * ((r) + 1) / 2 + (c)]
+    double Gf[36];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+            const double e = b[r] * b[c];
+            SLK_G(r, c) = ((r == c) ? 1.0 : 0.0) - (wave_inclusive_scan(e) - e);
+        }
+    // G_j = R R^T in place (R lower, its diagonal kept as reciprocals), y = R^-1 b, d = 1 - |y|^2, w = -R^-T y / sqrt(d)
+    double y[8];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double d = SLK_G(j, j);
+#pragma unroll
+        for (int p = 0; p < j; ++p) d = fma(-SLK_G(j, p), SLK_G(j, p), d);
+        ok = ok && (d > 0.0);
+        double sq, rs;
+        rsqrt_pivot(d, sq, rs);
+        SLK_G(j, j) = rs;
+#pragma unroll
+        for (int i = j + 1; i < 8; ++i) {
+            double v = SLK_G(i, j);
+#pragma unroll
+            for (int p = 0; p < j; ++p) v = fma(-SLK_G(i, p), SLK_G(j, p), v);
+            SLK_G(i, j) = v * rs;
+        }
+        double s = b[j];
+#pragma unroll
+        for (int p = 0; p < j; ++p) s = fma(-SLK_G(j, p), y[p], s);
+        y[j] = s * rs;
+    }
+    double dj = 1.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dj = fma(-y[c], y[c], dj);
+    ok = ok && (dj > 0.0);
+    double sqd, rsd;
+    rsqrt_pivot(dj, sqd, rsd);
+#pragma unroll
+    for (int c = 7; c >= 0; --c) {                   // w overwrites y from the back
+        double s = y[c];
+#pragma unroll
+        for (int p = c + 1; p < 8; ++p) s = fma(-SLK_G(p, c), y[p], s);
+        y[c] = s * SLK_G(c, c);
+        Wbuf[bw_idx(lane, c)] = live ? -y[c] * rsd : 0.0;
+    }
+#undef SLK_G
+    if (live) mdiag[lane] = sqd;
+    // rows beyond N never fail the test (their b is zero: d = 1)
+    return __all(ok) != 0;
+}
+
+// output tile (I, J) of the lower triangle -> the wave that computes it; MFMA cost of a tile is 6 (I - J + 1)
+template <int NT> __device__ __forceinline__ constexpr int ldm_tile_wave(int I, int J)
+{
+    if (NT == 4) return (I == 3) ? J : (I == 0 ? 0 : (J == 0 ? I : 3));          // 30 MFMAs per wave
+    return (I == 2) ? (J == 0 ? 0 : (J == 1 ? 1 : 3)) : (I == 0 ? 1 : 2);          // NT == 3: 18 / 18 / 18 / 6
+}
+
+// position of tile (I, J) among the tiles of its wave, in (I, J) iteration order: a compile-time accumulator index
+template <int NT> __device__ __forceinline__ constexpr int ldm_tile_slot(int I, int J)
+{
+    int n = 0;
+    for (int i = 0; i < NT; ++i)
+        for (int j = 0; j <= i; ++j) {
+            if (i == I && j == J) return n;
+            if (ldm_tile_wave<NT>(i, j) == ldm_tile_wave<NT>(I, J)) ++n;
+        }
+    return n;
+}
+
+// L <- L M on the matrix cores, in place in the packed factor.  Called by all NT <= 4 waves of a 256-thread workgroup;
+// two workgroup barriers inside.  acc tiles are U(J, I) = L'(I, J)^T: register r of lane (c, g) is L'[16 I + c][16 J + 4 r + g].
+template <int NT>
+__device__ __forceinline__ void ldm_product(double *Lp, int N, const double *Bbuf, const double *Wbuf, const double *mdiag,
+                                            int lane, int wave)
+{
+    const int c = lane & 15, g = lane >> 4, tri_g = (g * (g + 1)) >> 1;
+    constexpr int MAXT = (NT == 4) ? 4 : 2;          // most tiles a wave owns
+    d4 acc[MAXT];
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J) {
+            if (ldm_tile_wave<NT>(I, J) != wave) continue;
+            d4 a = {0.0, 0.0, 0.0, 0.0};
+            const double wf0 = Wbuf[bw_idx(16 * J + c, g)], wf1 = Wbuf[bw_idx(16 * J + c, 4 + g)];
+#pragma unroll
+            for (int K = J; K <= I; ++K) {
+                // M(K, J) = B_K W_J^T (+ the diagonal fix): result register r of lane (c, g) is M[16 K + g + 4 r][16 J + c]
+                d4 mt = {0.0, 0.0, 0.0, 0.0};
+                mt = __builtin_amdgcn_mfma_f64_16x16x4f64(Bbuf[bw_idx(16 * K + c, g)], wf0, mt, 0, 0, 0);
+                mt = __builtin_amdgcn_mfma_f64_16x16x4f64(Bbuf[bw_idx(16 * K + c, 4 + g)], wf1, mt, 0, 0, 0);
+                if (K == J) {
+                    const double dg = mdiag[(16 * J + c < N) ? 16 * J + c : 0];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = g + 4 * r;
+                        mt[r] = (row > c) ? mt[r] : ((row == c) ? dg : 0.0);
+                    }
+                }
+                // U(J, I) += M(K, J)^T L(I, K)^T: A = the M tile as it stands, B = fragment of L (lane (c, g): L[16 I + c][16 K + 4 s + g])
+                double lf[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int row = 16 * I + c, col = 16 * K + 4 * s + g;
+                    const bool in = row < N && col <= row;
+                    const double v = Lp[in ? packed_colbase(N, 16 * K + 4 * s, g, tri_g) + row : 0];
+                    lf[s] = in ? v : 0.0;
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a = __builtin_amdgcn_mfma_f64_16x16x4f64(mt[s], lf[s], a, 0, 0, 0);
+            }
+            acc[ldm_tile_slot<NT>(I, J)] = a;
+        }
+    __syncthreads();                                  // every wave has read what it needs of the old factor
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J) {
+            if (ldm_tile_wave<NT>(I, J) != wave) continue;
+            const d4 a = acc[ldm_tile_slot<NT>(I, J)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * I + c, col = 16 * J + 4 * r + g;
+                if (row < N && col <= row) Lp[packed_colbase(N, 16 * J + 4 * r, g, tri_g) + row] = a[r];
+            }
+        }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------ small reductions
 // sum over i in [0, cnt) of term(i), spread over G consecutive lanes (G = 2^k <= 64); every lane of
 // the group gets the total
@@ -808,7 +1009,7 @@ __device__ __forceinline__ void feature_proj_item(const Lay &L, const double *mp
     pose_of(L, (int)mp[4 * f + 3], tp, sp, b);
     const int j = (i > 0) ? ((i - 1) >> 1) : 0;
     const double sgn = (i == 0) ? 0.0 : ((i & 1) ? 1.0 : -1.0);
-    const int jb = ((j * (2 * n - j + 1)) >> 1) - j;                  // pk(n, t, j) = jb + t
+    const int jb = pkcol(n, j);                                       // pk(n, t, j) = jb + t
     double l[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) l[c] = Lp[(j <= tp + c) ? jb + tp + c : 0];
@@ -1277,7 +1478,10 @@ struct MfmaTiles32 {
 
 // ------------------------------------------------------------------ the Msckf step kernel
 // predict (optional) + UKF update with applyDelta (optional), one workgroup per filter.
-template <int NT, int NTHREADS>
+// KST >= 0: the number of sensor-pose clones is a compile-time constant (exact-shape instantiation: the layout and
+// packed-index arithmetic fold); KST < 0: taken from the arguments.
+// MST > 0: the number of measurement rows is a compile-time constant too (every LDS offset of the carve folds).
+template <int NT, int NTHREADS, int KST = -1, int MST = 0>
 __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? SLK_WGS : (NT == 5 ? 3 : ((NT >= 6 && NT <= 8) ? 2 : (NT <= 2 ? 4 : 1))))) void msckf_step_kernel(KArgs a)
 {
     constexpr bool BIG = NT > 5;                           // large state: factor + rotation store in the global workspace
@@ -1289,12 +1493,14 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
     const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Lay L = a.lay;
     L.kind = SLK_MSCKF;                                    // this kernel is the Msckf step: fold the layout branches
+    if constexpr (KST >= 0) { L.k = KST; L.N = 12 + 6 * KST; L.Nq = 13 + 7 * KST; L.nso3 = 1 + KST; }
+    if constexpr (MST > 0) { a.m = MST; a.rebuild_prec = 0; a.emit = 0; a.do_update = 1; }     // guaranteed by the launcher
     const int N = L.N, Nq = L.Nq, m = a.m, nso3 = L.nso3;
-    const Carve cv = carve_step(L, m, NT, BIG, a.rebuild_prec);
+    const Carve cv = carve_step(L, m, NT, BIG, (KST >= 0 && MST > 0) ? 0 : a.rebuild_prec);
     const int S = cv.S, LDD = cv.LDD;
     double *Lp = BIG ? a.wsL + (size_t)bidx * pk_size(N) : smem + cv.Lp;
     double *mu = smem + cv.mu, *ref = smem + cv.ref, *pn12 = smem + cv.pn12;
-    double *delta = smem + cv.delta, *md = smem + cv.md, *colbuf = smem + cv.colbuf, *pool = smem + cv.pool;
+    double *delta = smem + cv.delta, *md = smem + cv.md, *colbuf = smem + cv.colbuf, *pool = smem + cv.pool, *cq = smem + cv.cq;
     int *ish = reinterpret_cast<int *>(smem + cv.small);      // [0..MAXM) idx, [40] count, [41] outliers, [42] flag, [43] predicted
     int *roff = ish + 48;                                     // nso3 + 1 prefix offsets of the rotation items
     double *gmean = a.mean + (size_t)bidx * Nq;
@@ -1315,6 +1521,18 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
     }
     __syncthreads();
     SLK_STAMP(1);
+
+    // The tile rows of the covariance below the current state's 12 x 12 block do not depend on predict: the waves that
+    // own them for the first factorisation (one tile row per wave) fetch them now, while wave 0 runs the predict phase
+    // alone -- their global-load latency is off the critical path.
+    constexpr bool WCHOL = NT >= 3 && NT <= 4 && NW >= NT;       // one tile row per wave
+    d4 acc1[WCHOL ? NT : 1];
+    if constexpr (WCHOL) {
+#ifdef SLK_EARLY_LOAD
+        if ((a.do_update || a.emit >= 2) && wave > 0)
+            cholw_load<NT>(acc1, N, lane, wave, [&](int i, int j) { return gP[i + (size_t)j * N]; });
+#endif
+    }
 
     // ---- predict: Msckf.hpp:89-189 (state<->clone cross-covariances stay stale: :171-182).
     // Only the lower triangle of Pk is ever read by Msckf::predict/update (LLT at :412, :447).
@@ -1352,11 +1570,12 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
     if (a.do_update || a.emit >= 2) {
         // ---- sigma points of the full state: Msckf.hpp:228-229 -> :400-431
         int fail;
-        constexpr bool WCHOL = NT >= 3 && NT <= 4 && NW >= NT;   // one tile row per wave
         if constexpr (WCHOL) {
-            d4 acc[NT];
-            cholw_load<NT>(acc, N, lane, wave, Pin);
-            fail = cholw_factor<NT>(acc, Lp, N, colbuf, md, lane, wave, &ish[45]);
+#ifdef SLK_EARLY_LOAD
+            if (wave == 0)
+#endif
+            cholw_load<NT>(acc1, N, lane, wave, Pin);                     // tile row 0 holds the predicted block
+            fail = cholw_factor<NT>(acc1, Lp, N, colbuf, md, lane, wave, &ish[45]);
         } else if constexpr (NT <= 4) {
             if (wave == 0) {
                 d4 acc[CholM<NT>::NTL];
@@ -1495,6 +1714,10 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                                 gg[i][j] = v * rs;
                             }
                         }
+                        // applyDelta's factor as a factor UPDATE (L' = L M, see ldm_columns): needs covXZ = L A, i.e. no
+                        // wrapped rotation column; otherwise K is stored and the downdated matrix is factored afresh
+                        bool fastw = false;
+                        if constexpr (WCHOL) fastw = (f0 < 0) && ish[42] == 0;
                         if (f0 < 0) {
                             for (int t = lane; t < N; t += 64) {
                                 double x[8];
@@ -1505,15 +1728,39 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                                     for (int p = 0; p < c; ++p) sum = fma(-gg[c][p], x[p], sum);
                                     x[c] = sum * gi[c];
                                 }
+                                double dsum = 0.0;
 #pragma unroll
                                 for (int c = 7; c >= 0; --c) {            // backward: Ls^T x = w
                                     double sum = x[c];
 #pragma unroll
                                     for (int p = c + 1; p < 8; ++p) sum = fma(-gg[p][c], x[p], sum);
                                     x[c] = sum * gi[c];
-                                    if (c < mmr) K[t + N * c] = x[c];
+                                    if (!fastw && c < mmr) K[t + N * c] = x[c];
+                                }
+                                if (fastw) {                              // delta = K * innovation (:263), same order as below
+#pragma unroll
+                                    for (int c = 0; c < 8; ++c) dsum += (c < mmr) ? x[c] * innov[idx[c < mmr ? c : 0]] : 0.0;
+                                    delta[t] = dsum;
                                 }
                             }
+                        }
+                        if constexpr (WCHOL) {
+                            if (fastw) {
+                                // row `lane` of B = A Ls^-T: forward substitution on a = 1/2 (Z_{2j+1} - Z_{2j+2})
+                                double bb[8];
+                                const bool live = lane < N;
+#pragma unroll
+                                for (int c = 0; c < 8; ++c) {
+                                    const bool in = live && c < mmr;
+                                    const double dz = DZ[in ? lane * m + idx[c] : 0];
+                                    double sum = in ? 0.5 * dz : 0.0;
+#pragma unroll
+                                    for (int p = 0; p < c; ++p) sum = fma(-gg[c][p], bb[p], sum);
+                                    bb[c] = sum * gi[c];
+                                }
+                                const bool pd = ldm_columns(bb, lane, N, Z, Z + BW_SIZE, md);
+                                if (lane == 0) ish[47] = pd ? 1 : 2;
+                            } else if (lane == 0) ish[47] = 0;
                         }
                     } else if (mmr <= 16) {
                         d4 acc[CholM<1>::NTL];
@@ -1591,6 +1838,9 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                     status |= SLK_ST_SINGULAR;
                 } else {
                     // delta = K * innovation (:263)
+                    int fastw = 0;                                     // 1 / 2: the factor-update path ran (2: not positive definite)
+                    if constexpr (WCHOL) fastw = (mmr <= 8) ? ish[47] : 0;
+                    if (!fastw)
                     for (int t = tid; t < N; t += NTHREADS) {
                         double sum = 0.0;
                         for (int c = 0; c < mmr; ++c) sum += K[t + N * c] * innov[idx[c]];
@@ -1601,11 +1851,18 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                     // ---- Pk -= K S K^T (:262) fused into the load of applyDelta's Cholesky (:263 -> :659-662):
                     // K S = covXZ, so the downdated lower triangle is P(i,j) - sum_c covXZ(i,c) K(j,c).
                     if constexpr (WCHOL) {
-                        d4 acc[NT];
-                        cholw_load<NT>(acc, N, lane, wave, Pin);
-                        cholw_downdate<NT>(acc, N, mmr, lane, wave, [&](int r, int c) { return Pxz[r + N * idx[c]]; },
-                                           [&](int r, int c) { return K[r + N * c]; });
-                        fail = cholw_factor<NT>(acc, Lp, N, colbuf, md, lane, wave, &ish[45]);
+                        if (fastw == 1) {
+                            ldm_product<NT>(Lp, N, Z, Z + BW_SIZE, md, lane, wave);     // L <- L M on the matrix cores
+                            fail = -1;
+                        } else if (fastw == 2) {
+                            fail = 0;                                  // Pk - K S K^T is not positive definite
+                        } else {
+                            d4 acc[NT];
+                            cholw_load<NT>(acc, N, lane, wave, Pin);
+                            cholw_downdate<NT>(acc, N, mmr, lane, wave, [&](int r, int c) { return Pxz[r + N * idx[c]]; },
+                                               [&](int r, int c) { return K[r + N * c]; });
+                            fail = cholw_factor<NT>(acc, Lp, N, colbuf, md, lane, wave, &ish[45]);
+                        }
                     } else if constexpr (NT <= 4) {
                         if (wave == 0) {
                             d4 acc[CholM<NT>::NTL];
@@ -1650,8 +1907,11 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 int blk = 0, comp = 0, s = t2s(L, t, blk, comp);
                 if (s >= 0) ref[s] = mu[s] + delta[t];
             }
-            for (int b = tid; b < nso3; b += NTHREADS)
-                stq(ref + so3_soff(L, b), sigma_quat(L, mu, Lp, delta, b, sig_of(0)));
+            for (int b = tid; b < nso3; b += NTHREADS) {
+                const Quat qr = sigma_quat(L, mu, Lp, delta, b, sig_of(0));
+                stq(ref + so3_soff(L, b), qr);
+                stq(cq + 4 * b, qmul(qconj(qr), ldq(mu + so3_soff(L, b))));
+            }
             __syncthreads();
             int it = 0;
             double norm = 0.0;
@@ -1660,7 +1920,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 // rotation blocks of X_i [-] ref, only the sigma points whose block differs from X_0's
                 for (int w = tid; w < W; w += NTHREADS) {
                     double dx, dy, dz;
-                    rot_deviation_desc(a.rtab[w], mu, ref, Lp, delta, dx, dy, dz);
+                    rot_deviation_desc(a.rtab[w], cq, Lp, delta, dx, dy, dz);
                     DR[3 * w] = dx; DR[3 * w + 1] = dy; DR[3 * w + 2] = dz;
                 }
                 __syncthreads();
@@ -1689,7 +1949,9 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 }
                 for (int b = tid; b < nso3; b += NTHREADS) {
                     int to = msckf_toff(b), so = msckf_soff(b);
-                    stq(ref + so, qmul(ldq(ref + so), so3_exp(md[to], md[to + 1], md[to + 2])));
+                    const Quat qr = qmul(ldq(ref + so), so3_exp(md[to], md[to + 1], md[to + 2]));
+                    stq(ref + so, qr);
+                    stq(cq + 4 * b, qmul(qconj(qr), ldq(mu + so)));
                 }
                 __syncthreads();
                 if (!(norm > 1e-6 && ++it < 10000)) final_pass = true;
@@ -1722,7 +1984,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                     const int i = p0 + kk;
                     const int j = (i - 1) >> 1;
                     const double sgn = (i & 1) ? 1.0 : -1.0;
-                    const int jb = ((j * (2 * N - j + 1)) >> 1) - j;          // pk(N, t, j) = jb + t
+                    const int jb = pkcol(N, j);                               // pk(N, t, j) = jb + t
                     // all loads of this column first (branch-free: clamped address, select later)
                     double lv[RPT];
 #pragma unroll
@@ -1797,7 +2059,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                         const bool valid = i < S;
                         const int j = (i > 0) ? ((i - 1) >> 1) : 0;
                         const double sgn = (i == 0) ? 0.0 : ((i & 1) ? 1.0 : -1.0);
-                        const int jbc = ((j * (2 * N - j + 1)) >> 1) - j + c16;   // pk(N, t, j) = jbc + 16 I
+                        const int jbc = pkcol(N, j) + c16;                        // pk(N, t, j) = jbc + 16 I
                         const int i3 = 3 * i;
                         double frag[NT];
                         constexpr int ROWS_A = TileMap<NT>::row(HALF - 1) + 1;   // tile rows the first tile group touches
