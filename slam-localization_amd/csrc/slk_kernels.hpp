@@ -143,6 +143,14 @@ struct Carve {
 
 // big = large-state variant (NT > 5, i.e. N > 80): the packed factor and the rotation deviations live in a global
 // workspace, LDS keeps the small vectors, the measurement arrays, a Cholesky panel and the MFMA panels
+// doubles reserved for Z [S][m]; where the factor-update path can run (one tile row per wave, m <= 8) its W buffer
+// (BW_SIZE = 512 doubles) takes Z's place after the moments, so the region is at least that large
+__host__ __device__ inline int z_region(int S, int m, int NT, bool big)
+{
+    const int z = round_up(S * m, 2);
+    return (!big && NT >= 3 && NT <= 4 && m <= 8 && z < 512) ? 512 : z;
+}
+
 __host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT, bool big = false, int prec = 0)
 {
     const int N = L.N, Nq = L.Nq;
@@ -165,7 +173,7 @@ __host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT, bool bi
     c.pool = o;
     // measurement part: Z[S*m] (the gain K[N*m] reuses its place once the moments are done) DZ[N*m] Pxz[N*m]
     // Sm[m*m] G[m*(2m+1)] zbar innov
-    int upd1 = round_up(c.S * m, 2) + 2 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (2 * m + 1), 2)
+    int upd1 = z_region(c.S, m, NT, big) + 2 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (2 * m + 1), 2)
                + 4 * round_up(m, 2);
     // applyDelta part: rotation deviations (3 per item that differs from X_0) + the double-buffered panels of the
     // panel rebuild (N > 64, or the reduced-precision sweep); the K-split rebuild stages nothing
@@ -765,7 +773,8 @@ __device__ __forceinline__ int chol_blocked_mem(double *Lp, int n, double *panel
 //     G_j = I - sum_{k<j} b_k b_k^T  (8 x 8),  q_j = G_j^-1 b_j,  d_j = 1 - b_j . q_j,  w_j = -q_j / sqrt(d_j)
 // (Schur complements of I - B B^T through the Woodbury identity).  The G_j are PREFIX sums over the rows of B: one
 // wave scans them across its lanes (lane j = column j) and every lane factors its own 8 x 8 matrix -- no N-step serial
-// chain, no workgroup barrier -- and L M is a triangular matrix product on the matrix cores.
+// chain, no workgroup barrier -- and L M is a triangular matrix product on the matrix cores.  (ldm_prefix / ldm_columns
+// below work on T_j = Ls G_j Ls^T, which needs the deviations only.)
 
 // DPP moves of a double (two dwords); invalid source lanes read 0.0 (bound_ctrl)
 template <int CTRL, int ROW_MASK>
@@ -788,31 +797,50 @@ __device__ __forceinline__ double wave_inclusive_scan(double x)
     return x;
 }
 
-// B / W buffers: 64 rows x 8 columns, column pairs interleaved so that the two 16-lane halves of an MFMA operand read
+// W buffer: 64 rows x 8 columns, column pairs interleaved so that the two 16-lane halves of an MFMA operand read
 // (column 4s + g, g = 0 / 1) fall into one contiguous 32-double span: element (row, c) at (c >> 1) * 128 + 2 * row + (c & 1)
 __device__ __forceinline__ int bw_idx(int row, int c) { return (c >> 1) * 128 + 2 * row + (c & 1); }
 constexpr int BW_SIZE = 512;
 
-// One wave: lane j holds row j of B (zeros for j >= N and for columns >= m').  Writes Bbuf, Wbuf, mdiag[j] = sqrt(d_j).
-// Returns false if I - B B^T is not positive definite (uniform over the wave).
-__device__ __forceinline__ bool ldm_columns(const double (&b)[8], int lane, int N, double *Bbuf, double *Wbuf, double *mdiag)
-{
-    const bool live = lane < N;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) Bbuf[bw_idx(lane, c)] = live ? b[c] : 0.0;
-    // G_j = I - sum_{k<j} b_k b_k^T (lower triangle): inclusive scan minus the lane's own term
-    // Packed lower triangle: entry (r, c) at r (r + 1) / 2 + c.  (Running the six scan steps over all 36 entries at a
-    // time instead of entry by entry measured 0.5 % slower: more live registers.)
+// In terms of the measurement deviations themselves (b_j = Ls^-1 a_j, a_j = 1/2 (Z_{2j+1} - Z_{2j+2})):
+//     T_j = S - sum_{k<j} a_k a_k^T,  d_j = 1 - a_j . T_j^-1 a_j,  w~_j = -T_j^-1 a_j / sqrt(d_j),  M_ij = a_i . w~_j,
+// so the prefix sums need only the deviations -- they are taken EARLY, by a wave that would otherwise share the S / covXZ
+// tiles, and kept in its registers across the gate.  A measurement row the gate rejects drops out by replacing its
+// row / column of T_j with the identity and its component of a_j with zero.
+// Packed lower triangle of an 8 x 8 matrix: entry (r, c) at r (r + 1) / 2 + c.
 #define SLK_G(r, c) Gf[(r) * ((r) + 1) / 2 + (c)]
-    double Gf[36];
+__device__ __forceinline__ void ldm_prefix(const double (&a)[8], double (&Gf)[36])
+{
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
         for (int c = 0; c <= r; ++c) {
-            const double e = b[r] * b[c];
-            SLK_G(r, c) = ((r == c) ? 1.0 : 0.0) - (wave_inclusive_scan(e) - e);
+            const double e = a[r] * a[c];
+            SLK_G(r, c) = wave_inclusive_scan(e) - e;        // exclusive: sum over the lanes (columns) before this one
         }
-    // G_j = R R^T in place (R lower, its diagonal kept as reciprocals), y = R^-1 b, d = 1 - |y|^2, w = -R^-T y / sqrt(d)
+}
+
+// One wave, lane j = column j: Gf = prefix sums of ldm_prefix, a = this column's deviations (1/2 dZ), Sm = S (m x m,
+// column-major), kept = bit mask of the rows that survived the gate.  Writes Wbuf[j][:] = 1/2 w~_j (the factor 1/2 of
+// a_i = 1/2 dZ_i is folded in here, so that the product can read dZ as it stands) and mdiag[j] = sqrt(d_j).
+// Returns false if Pk - K S K^T is not positive definite (uniform over the wave).
+__device__ __forceinline__ bool ldm_columns(double (&Gf)[36], const double (&a)[8], const double *Sm, int m, unsigned kept,
+                                            int lane, int N, double *Wbuf, double *mdiag)
+{
+    const bool live = lane < N;
+    double b[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const bool kr = (kept >> r) & 1u;
+        b[r] = kr ? a[r] : 0.0;
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+            const bool in = kr && ((kept >> c) & 1u);
+            const double s = Sm[in ? r + m * c : 0];
+            SLK_G(r, c) = in ? s - SLK_G(r, c) : ((r == c) ? 1.0 : 0.0);
+        }
+    }
+    // T_j = R R^T in place (R lower, its diagonal kept as reciprocals), y = R^-1 b, d = 1 - |y|^2, w = -R^-T y / sqrt(d)
     double y[8];
     bool ok = true;
 #pragma unroll
@@ -842,19 +870,20 @@ __device__ __forceinline__ bool ldm_columns(const double (&b)[8], int lane, int 
     ok = ok && (dj > 0.0);
     double sqd, rsd;
     rsqrt_pivot(dj, sqd, rsd);
+    const double sc = -0.5 * rsd;
 #pragma unroll
     for (int c = 7; c >= 0; --c) {                   // w overwrites y from the back
         double s = y[c];
 #pragma unroll
         for (int p = c + 1; p < 8; ++p) s = fma(-SLK_G(p, c), y[p], s);
         y[c] = s * SLK_G(c, c);
-        Wbuf[bw_idx(lane, c)] = live ? -y[c] * rsd : 0.0;
+        Wbuf[bw_idx(lane, c)] = live ? y[c] * sc : 0.0;
     }
-#undef SLK_G
     if (live) mdiag[lane] = sqd;
-    // rows beyond N never fail the test (their b is zero: d = 1)
+    // (lanes beyond N carry a = 0 and the full prefix: d = 1, they never fail the test unless the real columns do)
     return __all(ok) != 0;
 }
+#undef SLK_G
 
 // output tile (I, J) of the lower triangle -> the wave that computes it; MFMA cost of a tile is 6 (I - J + 1)
 template <int NT> __device__ __forceinline__ constexpr int ldm_tile_wave(int I, int J)
@@ -878,7 +907,7 @@ template <int NT> __device__ __forceinline__ constexpr int ldm_tile_slot(int I, 
 // L <- L M on the matrix cores, in place in the packed factor.  Called by all NT <= 4 waves of a 256-thread workgroup;
 // two workgroup barriers inside.  acc tiles are U(J, I) = L'(I, J)^T: register r of lane (c, g) is L'[16 I + c][16 J + 4 r + g].
 template <int NT>
-__device__ __forceinline__ void ldm_product(double *Lp, int N, const double *Bbuf, const double *Wbuf, const double *mdiag,
+__device__ __forceinline__ void ldm_product(double *Lp, int N, const double *DZ, int m, const double *Wbuf, const double *mdiag,
                                             int lane, int wave)
 {
     const int c = lane & 15, g = lane >> 4, tri_g = (g * (g + 1)) >> 1;
@@ -895,10 +924,13 @@ __device__ __forceinline__ void ldm_product(double *Lp, int N, const double *Bbu
             const double wf0 = Wbuf[bw_idx(16 * J + c, g)], wf1 = Wbuf[bw_idx(16 * J + c, 4 + g)];
 #pragma unroll
             for (int K = J; K <= I; ++K) {
-                // M(K, J) = B_K W_J^T (+ the diagonal fix): result register r of lane (c, g) is M[16 K + g + 4 r][16 J + c]
+                // M(K, J) = dZ_K W_J^T (+ the diagonal fix): result register r of lane (c, g) is M[16 K + g + 4 r][16 J + c]
                 d4 mt = {0.0, 0.0, 0.0, 0.0};
-                mt = __builtin_amdgcn_mfma_f64_16x16x4f64(Bbuf[bw_idx(16 * K + c, g)], wf0, mt, 0, 0, 0);
-                mt = __builtin_amdgcn_mfma_f64_16x16x4f64(Bbuf[bw_idx(16 * K + c, 4 + g)], wf1, mt, 0, 0, 0);
+                const int arow = 16 * K + c;
+                const bool in0 = arow < N && g < m, in1 = arow < N && 4 + g < m;
+                const double a0 = DZ[in0 ? arow * m + g : 0], a1 = DZ[in1 ? arow * m + 4 + g : 0];
+                mt = __builtin_amdgcn_mfma_f64_16x16x4f64(in0 ? a0 : 0.0, wf0, mt, 0, 0, 0);
+                mt = __builtin_amdgcn_mfma_f64_16x16x4f64(in1 ? a1 : 0.0, wf1, mt, 0, 0, 0);
                 if (K == J) {
                     const double dg = mdiag[(16 * J + c < N) ? 16 * J + c : 0];
 #pragma unroll
@@ -1057,12 +1089,16 @@ __device__ __forceinline__ bool pose_params_ok(const KArgs &a, const Lay &L, con
 // Z = h(X) over the implicit sigma points of (mu, L), mean_z, innovation, S = 1/2 dZ dZ^T + R and
 // covXZ = 1/2 sum (X_i [-] mu)(Z_i - mean_z)^T  (Msckf.hpp:231-239, Usckf.hpp:277-283).
 // Lp = packed Cholesky factor.  *flag must be 0 on entry.
-template <int NTHREADS, class DiagFn>
+struct NoSpare { __device__ __forceinline__ void operator()() const {} };
+// `spare`: work for the LAST wave to run beside the S / covXZ tiles of the others (needs spare_ok, one S tile and no
+// wrapped rotation column; the wave then takes no tiles); *spare_ran tells whether it did.
+template <int NTHREADS, class DiagFn, class SpareFn = NoSpare>
 __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L, int bidx, int tid, const double *mu,
                                                     const double *Lp, double *Z, double *DZ, double *Pxz,
                                                     double *Sm, double *zbar, double *innov, int *flag,
                                                     DiagFn pdiag /* diagonal of the covariance Lp factors */,
-                                                    double *red = nullptr, int red_cap = 0)
+                                                    double *red = nullptr, int red_cap = 0,
+                                                    bool spare_ok = false, SpareFn spare = SpareFn(), bool *spare_ran = nullptr)
 {
     const int N = L.N, m = a.m, S = 2 * N + 1, nso3 = L.nso3;
     const double *mp = a.mp ? a.mp + (size_t)bidx * a.mp_stride : nullptr;
@@ -1142,8 +1178,18 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
     constexpr int NW = NTHREADS / 64;
     const int lane = tid & 63, wave = tid >> 6, fc = lane & 15, fg = lane >> 4;
     const int ntr = (N + 15) / 16, ntm = (m + 15) / 16;
+    const bool ksplit = NW > 1 && ntm == 1 && red && NW * m * m <= red_cap;
+    const bool spared = spare_ok && ksplit && !wrap && NW > 1;       // uniform over the workgroup
+    const int nwe = spared ? NW - 1 : NW;                            // waves that take tiles
+    if (spare_ran) *spare_ran = spared;
+    if (spared && wave == NW - 1) {
+        // (its own branch up to the first barrier below: what the hook leaves in registers must not span the tile code)
+        spare();
+        for (int e = lane; e < m * m; e += 64) red[wave * m * m + e] = 0.0;        // no partial S tile from this wave
+        SLK_STAMP_NR(16);
+    } else {
     if (!wrap) {
-        for (int e = wave; e < ntr * ntm; e += NW) {
+        for (int e = wave; e < ntr * ntm && wave < nwe; e += nwe) {
             const int I = e % ntr, jt = e / ntr, row = 16 * I + fc, cz = 16 * jt + fc;
             d4 acc = {0.0, 0.0, 0.0, 0.0};
             const int kend = (16 * I + 16 < N) ? (16 * I + 16) : N;
@@ -1186,12 +1232,12 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
         }
     }
     SLK_STAMP_NR(16);
-    if (NW > 1 && ntm == 1 && red && NW * m * m <= red_cap) {
+    if (ksplit) {
         // one S tile (m <= 16): the 2N+1 sigma points are split over the waves (32 per trip), the
         // partial m x m blocks meet in `red` (scratch of NW * m * m doubles)
         const double za = (fc < m) ? zbar[fc] : 0.0;
         d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
-        for (int k0 = 32 * wave; k0 < S; k0 += 32 * NW) {
+        for (int k0 = 32 * wave; k0 < S && wave < nwe; k0 += 32 * nwe) {
             double af[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1212,6 +1258,9 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
             const int orow = fg + 4 * r;
             if (orow < m && fc < m) red[wave * m * m + fc * m + orow] = acc0[r];
         }
+        }
+        }       // end of the tile waves' branch
+        if (ksplit) {
         __syncthreads();
         for (int e = tid; e < m * m; e += NTHREADS) {
             double sum = 0.0;
@@ -1618,7 +1667,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
         } else {
             // ---- pool carve for the measurement part
             double *Z = pool;                                   // [S][m]
-            double *DZ = Z + round_up(S * m, 2);                // [N][m]: Z_{2j+1} - Z_{2j+2}
+            double *DZ = Z + z_region(S, m, NT, BIG);           // [N][m]: Z_{2j+1} - Z_{2j+2}
             double *Pxz = DZ + round_up(N * m, 2);              // N x m (ld N)
             double *K = Z;                                      // N x m' (ld N): written after the moments, Z is dead then
             double *Sm = Pxz + round_up(N * m, 2);              // m x m (ld m)
@@ -1626,8 +1675,22 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
             double *zbar = G + round_up(m * (2 * m + 1), 2);
             double *innov = zbar + round_up(m, 2);
             int *idx = ish;
+            // factor-update path (see ldm_columns): the last wave scans the prefix sums of the measurement deviations
+            // while the others do the S / covXZ tiles, and keeps them in registers across the gate
+            double ldm_a[8], ldm_pf[36];
+            bool ldm_on = false;
+            auto ldm_scan = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const bool in = lane < N && c < m;
+                    const double dz = DZ[in ? lane * m + c : 0];
+                    ldm_a[c] = in ? 0.5 * dz : 0.0;
+                }
+                ldm_prefix(ldm_a, ldm_pf);
+            };
             measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lp, Z, DZ, Pxz, Sm, zbar, innov, &ish[42],
-                                           [&](int t) { return Pin(t, t); }, colbuf, cv.pool - cv.colbuf);
+                                           [&](int t) { return Pin(t, t); }, colbuf, cv.pool - cv.colbuf,
+                                           WCHOL && NW == 4 && m <= 8 && a.emit == 0, ldm_scan, &ldm_on);
             SLK_STAMP(6);
             // removeOutliers (:241 -> :723-754) incl. the shifted second erase (:741-744)
             if (tid == 0) {
@@ -1679,7 +1742,18 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 // K = covXZ * S^-1 (:257).  S = 1/2 dZ dZ^T + R is symmetric positive definite for any
                 // valid R: factor it (S = Ls Ls^T) and solve row-wise; a non-SPD S falls back to
                 // Gauss-Jordan with partial pivoting (the reference inverts with PartialPivLU).
-                if (wave == 0) {
+                // Beside it, the wave that holds the prefix sums turns them into the columns of the factor update
+                // (first branch: its 88 live registers must not span the S factorisation of wave 0).
+                if (WCHOL && wave == NW - 1) {
+                    int st47 = 0;
+                    if (ldm_on && mmr <= 8) {
+                        unsigned kept = 0;
+                        for (int r = 0; r < mmr; ++r) kept |= 1u << idx[r];
+                        const bool pd = ldm_columns(ldm_pf, ldm_a, Sm, m, kept, lane, N, Z, md);
+                        st47 = pd ? 1 : 2;
+                    }
+                    if (lane == 0) ish[47] = st47;
+                } else if (wave == 0) {
                     auto sel = [&](int i, int j) { return Sm[idx[i] + m * idx[j]]; };
                     int f0;
                     if (mmr <= 8) {
@@ -1716,8 +1790,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                         }
                         // applyDelta's factor as a factor UPDATE (L' = L M, see ldm_columns): needs covXZ = L A, i.e. no
                         // wrapped rotation column; otherwise K is stored and the downdated matrix is factored afresh
-                        bool fastw = false;
-                        if constexpr (WCHOL) fastw = (f0 < 0) && ish[42] == 0;
+                        const bool fastw = ldm_on && f0 < 0;
                         if (f0 < 0) {
                             for (int t = lane; t < N; t += 64) {
                                 double x[8];
@@ -1743,24 +1816,6 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                                     delta[t] = dsum;
                                 }
                             }
-                        }
-                        if constexpr (WCHOL) {
-                            if (fastw) {
-                                // row `lane` of B = A Ls^-T: forward substitution on a = 1/2 (Z_{2j+1} - Z_{2j+2})
-                                double bb[8];
-                                const bool live = lane < N;
-#pragma unroll
-                                for (int c = 0; c < 8; ++c) {
-                                    const bool in = live && c < mmr;
-                                    const double dz = DZ[in ? lane * m + idx[c] : 0];
-                                    double sum = in ? 0.5 * dz : 0.0;
-#pragma unroll
-                                    for (int p = 0; p < c; ++p) sum = fma(-gg[c][p], bb[p], sum);
-                                    bb[c] = sum * gi[c];
-                                }
-                                const bool pd = ldm_columns(bb, lane, N, Z, Z + BW_SIZE, md);
-                                if (lane == 0) ish[47] = pd ? 1 : 2;
-                            } else if (lane == 0) ish[47] = 0;
                         }
                     } else if (mmr <= 16) {
                         d4 acc[CholM<1>::NTL];
@@ -1839,7 +1894,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 } else {
                     // delta = K * innovation (:263)
                     int fastw = 0;                                     // 1 / 2: the factor-update path ran (2: not positive definite)
-                    if constexpr (WCHOL) fastw = (mmr <= 8) ? ish[47] : 0;
+                    if constexpr (WCHOL) fastw = (mmr <= 8 && sfail < 0) ? ish[47] : 0;
                     if (!fastw)
                     for (int t = tid; t < N; t += NTHREADS) {
                         double sum = 0.0;
@@ -1852,7 +1907,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                     // K S = covXZ, so the downdated lower triangle is P(i,j) - sum_c covXZ(i,c) K(j,c).
                     if constexpr (WCHOL) {
                         if (fastw == 1) {
-                            ldm_product<NT>(Lp, N, Z, Z + BW_SIZE, md, lane, wave);     // L <- L M on the matrix cores
+                            ldm_product<NT>(Lp, N, DZ, m, Z, md, lane, wave);          // L <- L M on the matrix cores
                             fail = -1;
                         } else if (fastw == 2) {
                             fail = 0;                                  // Pk - K S K^T is not positive definite
@@ -1918,10 +1973,28 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
             bool final_pass = false;
             for (;;) {                                        // :507-516, then one pass against the final mean (:584)
                 // rotation blocks of X_i [-] ref, only the sigma points whose block differs from X_0's
-                for (int w = tid; w < W; w += NTHREADS) {
-                    double dx, dy, dz;
-                    rot_deviation_desc(a.rtab[w], cq, Lp, delta, dx, dy, dz);
-                    DR[3 * w] = dx; DR[3 * w + 1] = dy; DR[3 * w + 2] = dz;
+                if constexpr (KST >= 0 && !BIG) {
+                    // exact shape: the item count is a compile-time constant -- all rounds of a thread as straight-line
+                    // code (index clamped, store predicated) so that their dependency chains interleave
+                    constexpr int WST = 6 * KST * KST + 31 * KST + 13;                 // msckf_roff(KST + 1)
+                    constexpr int RND = (WST + NTHREADS - 1) / NTHREADS;
+                    double dv[RND][3];
+#pragma unroll
+                    for (int r = 0; r < RND; ++r) {
+                        const int w = tid + r * NTHREADS;
+                        rot_deviation_desc(a.rtab[w < WST ? w : WST - 1], cq, Lp, delta, dv[r][0], dv[r][1], dv[r][2]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < RND; ++r) {
+                        const int w = tid + r * NTHREADS;
+                        if (w < WST) { DR[3 * w] = dv[r][0]; DR[3 * w + 1] = dv[r][1]; DR[3 * w + 2] = dv[r][2]; }
+                    }
+                } else {
+                    for (int w = tid; w < W; w += NTHREADS) {
+                        double dx, dy, dz;
+                        rot_deviation_desc(a.rtab[w], cq, Lp, delta, dx, dy, dz);
+                        DR[3 * w] = dx; DR[3 * w + 1] = dy; DR[3 * w + 2] = dz;
+                    }
                 }
                 __syncthreads();
                 if (final_pass) break;
