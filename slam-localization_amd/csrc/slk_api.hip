@@ -226,6 +226,21 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
         f->rtab_k = a.lay.k;
     }
     a.rtab = f->d_rtab;
+    if constexpr (NT >= 3 && NT <= 4) {
+        // the first factorisation runs in its own launch and hands the packed factor over through a workspace
+        int rc = stage_reserve(f, f->ws_L, (size_t)a.B * pk_size(a.lay.N));
+        if (rc) return rc;
+        rc = stage_reserve(f, f->ws_DR, ((size_t)a.B * sizeof(int) + sizeof(double) - 1) / sizeof(double));
+        if (rc) return rc;
+        a.wsL = f->ws_L.p;
+        a.wsfail = reinterpret_cast<int *>(f->ws_DR.p);
+        if (a.do_update || a.emit >= 2) {
+            auto ck = msckf_chol_kernel<NT, KST>;
+            const size_t clds = chol_kernel_lds<NT>(a.lay.N);
+            hipLaunchKernelGGL(ck, dim3(a.B), dim3(256), clds, f->stream, a);
+            HIPCHECK(hipGetLastError());
+        }
+    }
     if (BIG) {
         int rc = stage_reserve(f, f->ws_L, (size_t)a.B * pk_size(a.lay.N));
         if (rc) return rc;
@@ -254,8 +269,15 @@ static int launch_msckf_n60(slk_filter *f, const KArgs &a)
     return launch_msckf_inst<4, 256>(f, a);
 }
 
-static int launch_msckf(slk_filter *f, const KArgs &a)
+static int launch_msckf(slk_filter *f, const KArgs &a0)
 {
+    KArgs a = a0;
+    if (a.do_predict || a.emit == 1) {          // predict (or its Tier-B sigma-point emission): one wave per filter
+        hipLaunchKernelGGL(msckf_predict_kernel, dim3(a.B), dim3(64), 0, f->stream, a);
+        HIPCHECK(hipGetLastError());
+        if (!a.do_update) return SLK_OK;
+        a.do_predict = 0;                       // the step kernel takes the predicted state from memory
+    }
     int NT = (a.lay.N + 15) / 16;
 #ifdef SLK_DEV_N60      // development builds (tools/ab.sh): only the headline instantiations, for quick A/B turnarounds
     if (NT == 4) return launch_msckf_n60(f, a);

@@ -40,7 +40,8 @@ struct KArgs {
     int emit; double *Xout;     // 3 = checkSigmaPoints: re-draw, mean and covariance into mean_out / P_out
     double *mean_out, *P_out;   // null = in place
     int rebuild_prec;     // covariance rebuild arithmetic: 0 = fp64 (parity path), 1 = fp32 MFMA, 2 = bf16 inputs / fp32 accumulate
-    double *wsL, *wsDR;   // global workspaces of the large-state path (N > 80): packed factor, rotation deviations
+    double *wsL, *wsDR;   // global workspaces: packed factor (large states N > 80; factor hand-off of msckf_chol_kernel), rotation deviations
+    int *wsfail;          // msckf_chol_kernel -> step kernel: first non-positive pivot per filter, or -1
     const unsigned long long *rtab;   // Msckf: descriptors of the rotation items (layout only, built by the host)
     long long *dbg;   // phase stamps, diagnostic builds (-DSLK_STAMPS) only; always null in the product
     int stop;         // diagnostic builds: leave the kernel after this stamp (per-phase instruction counts)
@@ -137,7 +138,7 @@ __device__ __forceinline__ double Lz(const double *Lp, int n, int t, int j)
 
 // ------------------------------------------------------------------ LDS carve (in doubles)
 struct Carve {
-    int Lp, mu, ref, delta, md, cq, pn12, small, colbuf, pool, total;
+    int Lp, mu, ref, delta, md, cq, small, colbuf, pool, total;
     int S, LDD, TN, W;   // W = rotation-row items that differ from X_0 (sum over blocks of rot_count)
 };
 
@@ -167,7 +168,6 @@ __host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT, bool bi
     c.delta = o;  o += round_up(N, 2);
     c.md = o;     o += round_up(N, 2);
     c.cq = o;     o += 4 * L.nso3;                 // ref_b^-1 * mu_b per SO(3) block (mean loop)
-    c.pn12 = o;   o += 144;
     c.small = o;  o += 96;
     c.colbuf = o; o += big ? (4 * 34 + 136) : 4 * ((c.TN > 32 ? c.TN : 32) + 2);   // big: cholm<1..2> buffer + packed 16x16 factor
     c.pool = o;
@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
     const Carve cv = carve_step(L, m, NT, BIG, (KST >= 0 && MST > 0) ? 0 : a.rebuild_prec);
     const int S = cv.S, LDD = cv.LDD;
     double *Lp = BIG ? a.wsL + (size_t)bidx * pk_size(N) : smem + cv.Lp;
-    double *mu = smem + cv.mu, *ref = smem + cv.ref, *pn12 = smem + cv.pn12;
+    double *mu = smem + cv.mu, *ref = smem + cv.ref;
     double *delta = smem + cv.delta, *md = smem + cv.md, *colbuf = smem + cv.colbuf, *pool = smem + cv.pool, *cq = smem + cv.cq;
     int *ish = reinterpret_cast<int *>(smem + cv.small);      // [0..MAXM) idx, [40] count, [41] outliers, [42] flag, [43] predicted
     int *roff = ish + 48;                                     // nso3 + 1 prefix offsets of the rotation items
@@ -1566,65 +1566,28 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
         for (int b = 0; b < nso3; ++b) { roff[b] = o; o += rot_count(L, b); }
         roff[nso3] = o;
         ish[42] = 0;
-        ish[43] = 0;
     }
     __syncthreads();
     SLK_STAMP(1);
 
-    // The tile rows of the covariance below the current state's 12 x 12 block do not depend on predict: the waves that
-    // own them for the first factorisation (one tile row per wave) fetch them now, while wave 0 runs the predict phase
-    // alone -- their global-load latency is off the critical path.
+    // The predict step (Msckf.hpp:89-189) runs in its own launch (msckf_predict_kernel below): it touches the current
+    // state's 12 x 12 block only, keeps one wave busy per filter and nothing of it is reused on chip -- beside the
+    // four-wave phases of this kernel it held three waves and 38 KB of LDS idle for 13 % of the step.
     constexpr bool WCHOL = NT >= 3 && NT <= 4 && NW >= NT;       // one tile row per wave
-    d4 acc1[WCHOL ? NT : 1];
-    if constexpr (WCHOL) {
-#ifdef SLK_EARLY_LOAD
-        if ((a.do_update || a.emit >= 2) && wave > 0)
-            cholw_load<NT>(acc1, N, lane, wave, [&](int i, int j) { return gP[i + (size_t)j * N]; });
-#endif
-    }
-
-    // ---- predict: Msckf.hpp:89-189 (state<->clone cross-covariances stay stale: :171-182).
-    // Only the lower triangle of Pk is ever read by Msckf::predict/update (LLT at :412, :447).
-    if (a.do_predict || a.emit == 1) {
-        double *Lblk = pool, *Pn = pool + 160, *scr = pool + 320;   // 78 + 144 + (325+300+32+72)
-        if (wave == 0) {
-            __builtin_amdgcn_s_setprio(3);
-            int st0 = predict_phase<false>(a, bidx, tid, [&](int i, int j) { return gP[i + (size_t)j * N]; },
-                                           Lblk, mu, Pn, scr, nullptr);
-            __builtin_amdgcn_s_setprio(0);
-            if (tid == 0) ish[44] = st0;
-        }
-        __syncthreads();
-        const int st = ish[44];
-        if (a.emit == 1) return;
-        status |= st;
-        if (!(st & SLK_ST_LLT_FAIL)) {                // else: predict skipped, filter unchanged
-            for (int e = tid; e < 144; e += NTHREADS) {
-                int r = e % 12, c = e / 12;
-                gP[r + (size_t)c * N] = Pn[e];
-                pn12[e] = (r >= c) ? Pn[e] : Pn[c + 12 * r];     // on chip: lower triangle mirrored
-            }
-            for (int e = tid; e < 13; e += NTHREADS) gmean[e] = mu[e];
-            if (tid == 0) ish[43] = 1;
-        }
-        __syncthreads();
-    }
-    const bool predicted = ish[43] != 0;
-    // lower-triangle element of the (predicted) covariance: the fresh 12x12 block comes from LDS
-    auto Pin = [&](int i, int j) -> double {
-        return (predicted && i < 12) ? pn12[i + 12 * j] : gP[i + (size_t)j * N];
-    };
+    // lower-triangle element of the covariance (only the lower triangle of Pk is ever read: LLT at :412, :447)
+    auto Pin = [&](int i, int j) -> double { return gP[i + (size_t)j * N]; };
 
     SLK_STAMP(2);
     if (a.do_update || a.emit >= 2) {
         // ---- sigma points of the full state: Msckf.hpp:228-229 -> :400-431
         int fail;
         if constexpr (WCHOL) {
-#ifdef SLK_EARLY_LOAD
-            if (wave == 0)
-#endif
-            cholw_load<NT>(acc1, N, lane, wave, Pin);                     // tile row 0 holds the predicted block
-            fail = cholw_factor<NT>(acc1, Lp, N, colbuf, md, lane, wave, &ish[45]);
+            // the factor comes from msckf_chol_kernel (its own launch: a latency-bound phase that holds little LDS and
+            // few registers, run there at twice the residency this kernel can have), packed, L2-resident
+            const double *gL = a.wsL + (size_t)bidx * pk_size(N);
+            for (int e = tid; e < pk_size(N); e += NTHREADS) Lp[e] = gL[e];
+            fail = a.wsfail[bidx];
+            __syncthreads();
         } else if constexpr (NT <= 4) {
             if (wave == 0) {
                 d4 acc[CholM<NT>::NTL];
@@ -2289,6 +2252,65 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
         }
     }
     if (tid == 0 && status) atomicOr(a.status + bidx, status);
+}
+
+// ------------------------------------------------------------------ the Msckf factor kernel
+// generateSigmaPoints' Cholesky of the full covariance (Msckf.hpp:407-413, Eigen::LLT) for 32 < N <= 64: the four-wave
+// blocked factorisation on the fp64 matrix cores (cholw_factor), one workgroup per filter.  A chain of 15 short steps
+// with two barriers each: its throughput comes from workgroups per CU, and on its own it needs 15 KB of LDS and ~64
+// registers -- so it runs here at up to twice the residency of the step kernel (38 KB, 128 registers), and hands the
+// packed factor over through a workspace that stays in L2 / Infinity Cache.
+#ifndef SLK_CHOL_WAVES
+#define SLK_CHOL_WAVES 6
+#endif
+template <int NT, int KST = -1>
+__global__ __launch_bounds__(256, SLK_CHOL_WAVES) void msckf_chol_kernel(KArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = (KST >= 0) ? 12 + 6 * KST : a.lay.N;
+    const int PS = round_up(pk_size(N), 2);
+    double *Lp = smem, *colbuf = smem + PS, *coef = colbuf + CholM<NT>::COLBUF;
+    int *flag = reinterpret_cast<int *>(coef + 16);
+    const double *gP = a.P + (size_t)bidx * N * N;
+    d4 acc[NT];
+    cholw_load<NT>(acc, N, lane, wave, [&](int i, int j) { return gP[i + (size_t)j * N]; });
+    const int fail = cholw_factor<NT>(acc, Lp, N, colbuf, coef, lane, wave, flag);
+    double *gL = a.wsL + (size_t)bidx * pk_size(N);
+    for (int e = tid; e < pk_size(N); e += 256) gL[e] = Lp[e];
+    if (tid == 0) a.wsfail[bidx] = fail;
+}
+template <int NT> __host__ inline size_t chol_kernel_lds(int N)
+{
+    return (size_t)(round_up(pk_size(N), 2) + CholM<NT>::COLBUF + 16 + 2) * sizeof(double);
+}
+
+// ------------------------------------------------------------------ the Msckf predict kernel
+// Msckf::predict (Msckf.hpp:89-189; state <-> clone cross-covariances stay stale, :171-182): sigma points of the current
+// State's 12 x 12 block, process model, manifold mean, cov + Q.  One WAVE per filter (64-thread workgroups, 8.6 KB of
+// LDS): the phase is a chain of small dependent steps, so its throughput comes from many filters per SIMD -- up to
+// eight resident waves here against the single busy wave per four it had inside the fused step kernel.
+// Also the Tier-B halves: emit == 1 writes the 25 sigma points, pm == SLK_MODEL_EXTERNAL takes f(X) from Yext.
+#ifndef SLK_PRED_WAVES
+#define SLK_PRED_WAVES 4     // waves per SIMD the predict kernel is compiled for
+#endif
+__global__ __launch_bounds__(64, SLK_PRED_WAVES) void msckf_predict_kernel(KArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double sm[16 + 320 + 736];
+    const int bidx = blockIdx.x, tid = threadIdx.x;
+    const int N = a.lay.N, Nq = a.lay.Nq;
+    double *mu = sm, *Lblk = sm + 16, *Pn = sm + 16 + 160, *scr = sm + 16 + 320;   // 78 + 144 + (325+300+32+72)
+    double *gmean = a.mean + (size_t)bidx * Nq;
+    double *gP = a.P + (size_t)bidx * N * N;
+    if (tid < 13) mu[tid] = gmean[tid];
+    wave_sync();
+    const int st = predict_phase<false>(a, bidx, tid, [&](int i, int j) { return gP[i + (size_t)j * N]; }, Lblk, mu, Pn, scr, nullptr);
+    if (st < 0) return;                              // sigma points emitted
+    if (!(st & SLK_ST_LLT_FAIL)) {                   // else: predict skipped, filter unchanged
+        for (int e = tid; e < 144; e += 64) gP[(e % 12) + (size_t)(e / 12) * N] = Pn[e];
+        if (tid < 13) gmean[tid] = mu[tid];
+    }
+    if (tid == 0 && st) atomicOr(a.status + bidx, st);
 }
 
 // ------------------------------------------------------------------ MFMA fragment layout self test

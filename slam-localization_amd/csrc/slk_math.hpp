@@ -99,7 +99,10 @@ __device__ __forceinline__ void so3_log(const Quat &q, double &vx, double &vy, d
     const double w2 = q.w * q.w;
     double s;
     if (q.w > 0.0 && n2 * 16.0 < w2) {
-        const double rw = 1.0 / q.w;
+        // 1 / w by v_rcp_f64 and two Newton steps (to about an ulp) instead of the IEEE division sequence
+        double rw = __builtin_amdgcn_rcp(q.w);
+        rw = fma(fma(-q.w, rw, 1.0), rw, rw);
+        rw = fma(fma(-q.w, rw, 1.0), rw, rw);
         const double y = -(n2 * rw * rw);
         double f = 1.0 / 25.0;                    // (1/16)^13 / 27 < 9e-18: below a tenth of an ulp
         f = fma(f, y, 1.0 / 23.0);

@@ -197,8 +197,9 @@ def test_api_misuse_is_rejected(slk):
     assert lib.slk_update(f._h, 77, None, 0, z.ctypes.data, 2, R.ctypes.data, 0, 1, slk.HOST) == slk.E_INVALID
     assert lib.slk_predict(f._h, slk.PM_DELTA_POSE, None, 0, None, 0, slk.HOST) == slk.E_INVALID
     big = slk.Msckf(np.tile(o.identity_state(o.layout(o.MULTI, 40)), (1, 1)), np.eye(252))
-    with pytest.raises(slk.SlkError):
-        big.predict(slk.PM_DELTA_POSE, s["u"][0], s["Q"])      # N = 252 exceeds what the kernels are built for (208)
+    big.predict(slk.PM_DELTA_POSE, s["u"][0], s["Q"])          # predict touches the 12 x 12 block only: any window length
+    with pytest.raises(slk.SlkError):                          # N = 252 exceeds what the update kernels are built for (208)
+        big.update(np.zeros((1, 2)), slk.MM_FEATURE_PROJ, np.array([0.0, 0.0, 5.0, 1.0]), 0.01 * np.eye(2))
 
 
 # ------------------------------------------------------------------ full-size properties (BASELINE cfg3)
