@@ -2048,8 +2048,170 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 }
             };
             bool rebuilt = false;
-            if constexpr (NT <= 4) {
+            if constexpr (NW == 4 && NT >= 3 && NT <= 4) {
                 if (a.rebuild_prec == 0) {
+                    // ---- Odd / even rebuild.  The sigma points come in pairs X(2j+1), X(2j+2) = mu [+] (delta +- L_j):
+                    //     1/2 sum_i d_i d_i^T = 1/2 d_0 d_0^T + sum_j (o_j o_j^T + e_j e_j^T),   o = (d+ - d-)/2, e = (d+ + d-)/2.
+                    // Vector rows: o = L'(:, j), e = 0 (exactly, up to the rounding of mu + delta).  Rotation rows: the odd /
+                    // even parts of the stored deviations; beyond the block's columns (j > toff + 2) o = 0 and e = d_0.
+                    // So P+ = O O^T + E E^T + 1/2 d_0 d_0^T with HALF the k-steps of 1/2 D D^T for the N x N part, fragments
+                    // read as they lie in the packed factor / the deviation store, and E E^T a 27 x 27 problem in the index
+                    // space of the rotation rows (3 tiles), added where the tiles leave for memory.
+                    for (int w = tid; w < W; w += NTHREADS) {
+                        if ((((unsigned)a.rtab[w]) >> 18 & 3u) == 1u) {          // a '+' item: its '-' partner follows
+#pragma unroll
+                            for (int comp = 0; comp < 3; ++comp) {
+                                const double dp = DR[3 * w + comp], dm = DR[3 * w + 3 + comp];
+                                DR[3 * w + comp] = 0.5 * (dp - dm);
+                                DR[3 * w + 3 + comp] = 0.5 * (dp + dm);
+                            }
+                        }
+                    }
+                    if (tid == 0) md[0] = 0.0;                                  // the zero every masked fragment reads
+                    __syncthreads();
+                    constexpr int NTL = CholM<NT>::NTL;
+                    constexpr int HALF = (NTL + 1) / 2;                         // tiles per tile group
+                    const int th = wave >> 1, kh = wave & 1;                    // tile group, k-step group
+                    const int c16 = lane & 15, g4 = lane >> 4;
+                    const char *lds = reinterpret_cast<const char *>(smem);
+                    const int LpB = 8 * (int)(Lp - smem), DRB = 8 * (int)(DR - smem), zeroB = 8 * (int)(md - smem);
+                    int baseB[NT], thr[NT];
+                    bool isv[NT];
+#pragma unroll
+                    for (int I = 0; I < NT; ++I) {
+                        const int tr = 16 * I + c16;
+                        int blk = 0, comp = 0;
+                        isv[I] = true; thr[I] = -1; baseB[I] = zeroB;
+                        if (tr < N) {
+                            const int s = t2s(L, tr, blk, comp);
+                            if (s >= 0) { thr[I] = tr; baseB[I] = LpB + 8 * tr; }
+                            else { isv[I] = false; thr[I] = msckf_toff(blk) + 2; baseB[I] = DRB + 8 * (3 * msckf_roff(blk) + comp + 3); }
+                        }
+                    }
+                    d4 acc[HALF];
+#pragma unroll
+                    for (int q = 0; q < HALF; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+                    const int nks = (N + 3) >> 2;
+                    constexpr int ROWS_A = TileMap<NT>::row(HALF - 1) + 1;       // tile rows the first tile group touches
+                    for (int ks = kh; ks < nks; ks += 2) {
+                        const int j = 4 * ks + g4;
+                        const int varV = 8 * pkcol(N, j), varR = 48 * j;
+                        double frag[NT];
+#pragma unroll
+                        for (int I = 0; I < NT; ++I) {
+                            if (I >= ROWS_A && th == 0) { frag[I] = 0.0; continue; }
+                            const bool c = j <= thr[I];
+                            const int ad = c ? baseB[I] + (isv[I] ? varV : varR) : zeroB;
+                            frag[I] = *reinterpret_cast<const double *>(lds + ad);
+                        }
+#pragma unroll
+                        for (int I = 0; I < NT; ++I)
+#pragma unroll
+                            for (int J = 0; J <= I; ++J)
+                                if (tile_idx(I, J) / HALF == th)
+                                    acc[tile_idx(I, J) % HALF] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                                        frag[I], frag[J], acc[tile_idx(I, J) % HALF], 0, 0, 0);
+                    }
+                    // E E^T + 1/2 d_0 d_0^T in the index space of the rotation rows: rho = 3 b + comp, tiles (0,0) (1,0) (1,1)
+                    // by waves 0, 1, 2
+                    d4 accE = {0.0, 0.0, 0.0, 0.0};
+                    if (wave < 3) {
+                        const int Ir = wave >= 1 ? 1 : 0, Ic = wave == 2 ? 1 : 0;
+                        const int nrot = 3 * nso3;
+                        int bE[2], tE[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int rho = 16 * (u ? Ic : Ir) + c16;
+                            const int b = rho / 3, comp = rho - 3 * b;
+                            const bool okr = rho < nrot;
+                            bE[u] = okr ? DRB + 8 * (3 * msckf_roff(okr ? b : 0) + comp) : -1;
+                            tE[u] = msckf_toff(okr ? b : 0) + 2;
+                        }
+                        for (int ks = 0; ks < nks; ++ks) {
+                            const int j = 4 * ks + g4;
+                            double fe[2];
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const int ad = (bE[u] >= 0 && j < N) ? bE[u] + (j <= tE[u] ? 48 * j + 48 : 0) : zeroB;
+                                fe[u] = *reinterpret_cast<const double *>(lds + ad);
+                            }
+                            accE = __builtin_amdgcn_mfma_f64_16x16x4f64(fe[0], fe[1], accE, 0, 0, 0);
+                        }
+                        double f0[2];                                            // the centre point: 1/2 d_0 d_0^T
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const double d0 = *reinterpret_cast<const double *>(lds + ((bE[u] >= 0 && g4 == 0) ? bE[u] : zeroB));
+                            f0[u] = d0 * 0.70710678118654752440;
+                        }
+                        accE = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[0], f0[1], accE, 0, 0, 0);
+                    }
+                    __syncthreads();                     // factor, deviations and vectors are dead from here
+                    SLK_STAMP(14);
+                    constexpr int TS = 16 * 17;          // padded 16x16 tile, [col][row]
+                    double *EEt = smem + (cv.total - 3 * TS);
+                    int TR = (cv.total - 3 * TS) / (2 * TS);
+                    if (TR > NTL) TR = NTL;
+                    double *red = smem;
+                    if (wave < 3) {
+                        double *dst = EEt + wave * TS + c16 * 17 + g4;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dst[4 * q] = accE[q];
+                    }
+                    const int ea = tid & 15, eb = (tid >> 4) & 15;
+                    // rotation-row index of a tangent row (-1: a vector row or padding): State.hpp:141-149, :246-252, :384-396
+                    auto rho_of = [&](int tr) -> int {
+                        if (tr >= N) return -1;
+                        if (tr < 12) return (tr >= 3 && tr < 6) ? tr - 3 : -1;
+                        const int cc = (tr - 12) / 6, r = (tr - 12) - 6 * cc;
+                        return r >= 3 ? 3 + 3 * cc + (r - 3) : -1;
+                    };
+                    int rra[NT], rrb[NT];
+#pragma unroll
+                    for (int I = 0; I < NT; ++I) { rra[I] = rho_of(16 * I + ea); rrb[I] = rho_of(16 * I + eb); }
+                    auto ee_val = [&](int r1, int r2) -> double {
+                        const int hi = r1 > r2 ? r1 : r2, lo = r1 > r2 ? r2 : r1;
+                        const bool in = lo >= 0;
+                        const double v = EEt[in ? ((hi >> 4) + (lo >> 4)) * TS + (lo & 15) * 17 + (hi & 15) : 0];
+                        return in ? v : 0.0;
+                    };
+                    for (int T0 = 0; T0 < NTL; T0 += TR) {
+#pragma unroll
+                        for (int T = 0; T < NTL; ++T)
+                            if (T / HALF == th && T >= T0 && T < T0 + TR) {
+                                double *dst = red + (kh * TR + (T - T0)) * TS + c16 * 17 + g4;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) dst[4 * q] = acc[T % HALF][q];
+                            }
+                        __syncthreads();
+                        const int ntl = (NTL - T0 < TR) ? NTL - T0 : TR;
+                        for (int Tl = 0; Tl < ntl; ++Tl) {                       // 256 threads per tile; tile index uniform
+                            const int T = T0 + Tl;
+                            const int I = (T >= 1) + (T >= 3) + (T >= 6), J = T - I * (I + 1) / 2;
+                            const double *src = red + Tl * TS;
+                            int ra = rra[0], rbI = rrb[0], raJ = rra[0], rb = rrb[0];
+#pragma unroll
+                            for (int q = 1; q < NT; ++q) {
+                                if (I == q) { ra = rra[q]; rbI = rrb[q]; }
+                                if (J == q) { raJ = rra[q]; rb = rrb[q]; }
+                            }
+                            {   // lower triangle: consecutive lanes = consecutive rows of one column
+                                const double sum = src[eb * 17 + ea] + src[TR * TS + eb * 17 + ea] + ee_val(ra, rb);
+                                const int row = 16 * I + ea, col = 16 * J + eb;
+                                if (row < N && col < N) oP[row + (size_t)col * N] = sum;
+                            }
+                            if (I != J) {   // mirrored copy, again contiguous in the fast index
+                                const double sum = src[ea * 17 + eb] + src[TR * TS + ea * 17 + eb] + ee_val(rbI, raJ);
+                                const int row = 16 * I + eb, col = 16 * J + ea;
+                                if (row < N && col < N) oP[col + (size_t)row * N] = sum;
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    rebuilt = true;
+                }
+            }
+            if constexpr (NT <= 4) {
+                if (!rebuilt && a.rebuild_prec == 0) {
                     // ---- K-split rebuild: every wave owns ALL lower tiles for its share of the sigma
                     // points (k-steps dealt round-robin), builds its A/B fragments straight from the
                     // packed factor / the rotation deviations -- no panel staging, no barrier, no

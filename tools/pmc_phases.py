@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--clones", type=int, default=8)
     ap.add_argument("--meas", type=int, default=8)
     ap.add_argument("--report", default=None)
+    ap.add_argument("--lib", default=None, help="a stamps build made elsewhere (build.py --dev NAME --stamps), e.g. ab/NAME.so")
     args = ap.parse_args()
     if args.report:
         return report(args.report, args.batch)
@@ -56,7 +57,7 @@ def main():
     spec = importlib.util.spec_from_file_location("slk_build", os.path.join(ROOT, "slam-localization_amd", "build.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    so = b.build(stamps=True)
+    so = os.path.join(ROOT, args.lib) if args.lib else b.build(stamps=True)
     from slkpkg import slk
     import scenarios as sc
     lib = slk.load_library(so)

@@ -17,7 +17,7 @@ f, name = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for row in csv.DictReader(open(f)):
     k = row["Kernel_Name"]
-    if "msckf_step" not in k: continue
+    if "msckf_" not in k: continue
     acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); 
     n[(k, row["Counter_Name"])] += 1
 for k in acc:
