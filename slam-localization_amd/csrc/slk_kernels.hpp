@@ -943,8 +943,10 @@ __device__ __forceinline__ void ldm_product(double *Lp, int N, const double *DZ,
                 double lf[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
+                    // (K < I: the tile lies below the diagonal, every column is <= every row; only the last tile row can
+                    // run past N -- both known at compile time in the unrolled loops)
                     const int row = 16 * I + c, col = 16 * K + 4 * s + g;
-                    const bool in = row < N && col <= row;
+                    const bool in = (I < NT - 1 || row < N) && (K < I || col <= row);
                     const double v = Lp[in ? packed_colbase(N, 16 * K + 4 * s, g, tri_g) + row : 0];
                     lf[s] = in ? v : 0.0;
                 }
@@ -1934,6 +1936,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
             int it = 0;
             double norm = 0.0;
             bool final_pass = false;
+            const bool oe_rebuild = NW == 4 && NT >= 3 && NT <= 4 && a.rebuild_prec == 0;
             for (;;) {                                        // :507-516, then one pass against the final mean (:584)
                 // rotation blocks of X_i [-] ref, only the sigma points whose block differs from X_0's
                 if constexpr (KST >= 0 && !BIG) {
@@ -1990,7 +1993,13 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                     stq(cq + 4 * b, qmul(qconj(qr), ldq(mu + so)));
                 }
                 __syncthreads();
-                if (!(norm > 1e-6 && ++it < 10000)) final_pass = true;
+                if (!(norm > 1e-6 && ++it < 10000)) {
+                    // The loop leaves with |mean_delta| <= 1e-6 (:511): the deviations against the final mean follow from the
+                    // ones just taken by a first-order correction (below, error O(|mean_delta|^2) <= 1e-12) -- the odd / even
+                    // rebuild applies it while it pairs the items, the other rebuilds take one more full pass.
+                    if (oe_rebuild && it < 10000) break;
+                    final_pass = true;
+                }
             }
             if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
             SLK_STAMP(12);
@@ -2057,14 +2066,35 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                     // So P+ = O O^T + E E^T + 1/2 d_0 d_0^T with HALF the k-steps of 1/2 D D^T for the N x N part, fragments
                     // read as they lie in the packed factor / the deviation store, and E E^T a 27 x 27 problem in the index
                     // space of the rotation rows (3 tiles), added where the tiles leave for memory.
+                    // The stored deviations are against the reference BEFORE its last move m = mean_delta (|m| <= 1e-6): against
+                    // the final mean  d' = log(exp(-m) exp(d)) = d - Jl^-1(d) m + O(|m|^2),
+                    //     Jl^-1(d) m = m - 1/2 d x m + a d x (d x m),  a = 1/|d|^2 - (1 + cos|d|) / (2 |d| sin|d|) = 1/12 + |d|^2/720 + ...
+                    // (left Jacobian of SO(3); the next terms are below 1e-12 for the rotations a sigma point spreads).  After a
+                    // non-converged loop (max_it, status flagged) the stored deviations are already the final pass.
+                    const bool corr = it < 10000;
                     for (int w = tid; w < W; w += NTHREADS) {
-                        if ((((unsigned)a.rtab[w]) >> 18 & 3u) == 1u) {          // a '+' item: its '-' partner follows
-#pragma unroll
-                            for (int comp = 0; comp < 3; ++comp) {
-                                const double dp = DR[3 * w + comp], dm = DR[3 * w + 3 + comp];
-                                DR[3 * w + comp] = 0.5 * (dp - dm);
-                                DR[3 * w + 3 + comp] = 0.5 * (dp + dm);
-                            }
+                        const unsigned lo = (unsigned)a.rtab[w];
+                        const unsigned sc = (lo >> 18) & 3u;
+                        if (sc == 2u) continue;                                  // a '-' item: done by its '+' partner
+                        const int to = (lo >> 20) & 0xff;
+                        const double m0 = corr ? md[to] : 0.0, m1 = corr ? md[to + 1] : 0.0, m2 = corr ? md[to + 2] : 0.0;
+                        auto fix = [&](double &x, double &y, double &z) {
+                            const double cx = y * m2 - z * m1, cy = z * m0 - x * m2, cz = x * m1 - y * m0;      // d x m
+                            const double ax = y * cz - z * cy, ay = z * cx - x * cz, az = x * cy - y * cx;      // d x (d x m)
+                            const double a12 = 1.0 / 12.0 + (x * x + y * y + z * z) * (1.0 / 720.0);
+                            x = x - m0 + 0.5 * cx - a12 * ax;
+                            y = y - m1 + 0.5 * cy - a12 * ay;
+                            z = z - m2 + 0.5 * cz - a12 * az;
+                        };
+                        double px = DR[3 * w], py = DR[3 * w + 1], pz = DR[3 * w + 2];
+                        fix(px, py, pz);
+                        if (sc == 0u) {                                          // the centre point
+                            DR[3 * w] = px; DR[3 * w + 1] = py; DR[3 * w + 2] = pz;
+                        } else {                                                 // a '+' item: its '-' partner follows
+                            double qx = DR[3 * w + 3], qy = DR[3 * w + 4], qz = DR[3 * w + 5];
+                            fix(qx, qy, qz);
+                            DR[3 * w] = 0.5 * (px - qx); DR[3 * w + 1] = 0.5 * (py - qy); DR[3 * w + 2] = 0.5 * (pz - qz);
+                            DR[3 * w + 3] = 0.5 * (px + qx); DR[3 * w + 4] = 0.5 * (py + qy); DR[3 * w + 5] = 0.5 * (pz + qz);
                         }
                     }
                     if (tid == 0) md[0] = 0.0;                                  // the zero every masked fragment reads
