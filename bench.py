@@ -243,7 +243,10 @@ def main():
                     "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/pmc_traffic.json",
                     "algorithmic_bytes_per_launch": algorithmic_bytes(N, Nq, m) * B,
-                    "kernel": "msckf_step_kernel", "kernel_ms": kernel_ms,
+                    "kernel": ("msckf_predict_kernel + msckf_chol_kernel + msckf_step_kernel (one filter step = three launches; "
+                               "kernel_ms = their summed duration per step, HIP events on the launch stream)") if 32 < N <= 64
+                              else "msckf_predict_kernel + msckf_step_kernel",
+                    "kernel_ms": kernel_ms,
                     "flops_per_filter_step": flops, "fp64_TFLOPs": achieved, "fp64_frac": achieved / PEAK_FP64_MFMA_TFLOPS,
                     "hbm_algorithmic_GBs": hbm, "hbm_frac": hbm / PEAK_HBM_GBS}
         out = {

@@ -227,19 +227,31 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
     }
     a.rtab = f->d_rtab;
     if constexpr (NT >= 3 && NT <= 4) {
-        // the first factorisation runs in its own launch and hands the packed factor over through a workspace
+        // Three launches per step: predict (one wave per filter), the first factorisation (its own residency, the packed
+        // factor handed over through a workspace), update + applyDelta.
         int rc = stage_reserve(f, f->ws_L, (size_t)a.B * pk_size(a.lay.N));
         if (rc) return rc;
         rc = stage_reserve(f, f->ws_DR, ((size_t)a.B * sizeof(int) + sizeof(double) - 1) / sizeof(double));
         if (rc) return rc;
         a.wsL = f->ws_L.p;
         a.wsfail = reinterpret_cast<int *>(f->ws_DR.p);
-        if (a.do_update || a.emit >= 2) {
-            auto ck = msckf_chol_kernel<NT, KST>;
-            const size_t clds = chol_kernel_lds<NT>(a.lay.N);
-            hipLaunchKernelGGL(ck, dim3(a.B), dim3(256), clds, f->stream, a);
+        const size_t lds = (size_t)cv.total * sizeof(double);
+        auto kern = msckf_step_kernel<NT, NTHREADS, KST, MST>;
+        rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), f->cfg.device, lds);
+        if (rc) return rc;
+        auto run_part = [&](KArgs s, hipStream_t st) -> int {
+            if (s.do_predict) {
+                hipLaunchKernelGGL(msckf_predict_kernel, dim3(s.B), dim3(64), 0, st, s);
+                HIPCHECK(hipGetLastError());
+                s.do_predict = 0;                   // the step kernel takes the predicted state from memory
+            }
+            hipLaunchKernelGGL((msckf_chol_kernel<NT, KST>), dim3(s.B), dim3(256), chol_kernel_lds<NT>(s.lay.N), st, s);
             HIPCHECK(hipGetLastError());
-        }
+            hipLaunchKernelGGL(kern, dim3(s.B), dim3(NTHREADS), lds, st, s);
+            HIPCHECK(hipGetLastError());
+            return SLK_OK;
+        };
+        return run_part(a, f->stream);
     }
     if (BIG) {
         int rc = stage_reserve(f, f->ws_L, (size_t)a.B * pk_size(a.lay.N));
@@ -272,13 +284,14 @@ static int launch_msckf_n60(slk_filter *f, const KArgs &a)
 static int launch_msckf(slk_filter *f, const KArgs &a0)
 {
     KArgs a = a0;
-    if (a.do_predict || a.emit == 1) {          // predict (or its Tier-B sigma-point emission): one wave per filter
+    int NT = (a.lay.N + 15) / 16;
+    const bool inside = (NT == 3 || NT == 4) && a.do_predict && a.do_update && a.emit == 0;   // launched per half-batch there
+    if ((a.do_predict || a.emit == 1) && !inside) {   // predict (or its Tier-B sigma-point emission): one wave per filter
         hipLaunchKernelGGL(msckf_predict_kernel, dim3(a.B), dim3(64), 0, f->stream, a);
         HIPCHECK(hipGetLastError());
         if (!a.do_update) return SLK_OK;
         a.do_predict = 0;                       // the step kernel takes the predicted state from memory
     }
-    int NT = (a.lay.N + 15) / 16;
 #ifdef SLK_DEV_N60      // development builds (tools/ab.sh): only the headline instantiations, for quick A/B turnarounds
     if (NT == 4) return launch_msckf_n60(f, a);
     g_err = "development build: N = 49..64 only"; return SLK_E_UNSUPPORTED;
