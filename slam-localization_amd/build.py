@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "slk_api.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("slk_api.hip", "slk_kernels.hpp", "slk_usckf.hpp", "slk_math.hpp", "slk_ekf.hpp", "slk_pose.hpp")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("slk_api.hip", "slk_kernels.hpp", "slk_usckf.hpp", "slk_math.hpp", "slk_ekf.hpp", "slk_ekf_tiles.hpp", "slk_pose.hpp")]
 DEPS.append(os.path.join(os.path.dirname(HERE), "include", "slk.h"))
 OUT = os.path.join(HERE, "libslk_hip.so")
 

@@ -17,6 +17,7 @@
 #include "slk_kernels.hpp"
 #include "slk_usckf.hpp"
 #include "slk_ekf.hpp"
+#include "slk_ekf_tiles.hpp"
 #include "slk_pose.hpp"
 
 using namespace slk;
@@ -656,9 +657,9 @@ int slk_update_ekf(slk_filter *f, const double *z, const double *zmean, const do
 #ifdef SLK_DEV_N60
     g_err = "development build: no EKF kernels"; return SLK_E_UNSUPPORTED;
 #else
-    const size_t lds = ekf_lds_doubles(N, m) * sizeof(double);
-    if (m <= 128 && N <= 64 && lds <= 140 * 1024) {               // factorisations, QR and thinQ resident in LDS
-        auto kern = msckf_ekf_lds_kernel<1024>;
+    const size_t lds = ekf_tile_lds_doubles(N, m) * sizeof(double);
+    if (m <= 128 && N <= 64) {                                    // everything resident in LDS as 16 x 16 tiles
+        auto kern = msckf_ekf_tile_kernel<1024>;
         rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), f->cfg.device, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(kern, dim3(f->B), dim3(1024), lds, f->stream, a);
