@@ -294,7 +294,9 @@ static int launch_msckf(slk_filter *f, const KArgs &a0)
         a.do_predict = 0;                       // the step kernel takes the predicted state from memory
     }
 #ifdef SLK_DEV_N60      // development builds (tools/ab.sh): only the headline instantiations, for quick A/B turnarounds
+#ifndef SLK_DEV_EKF     // (-DSLK_DEV_EKF: only the EKF tile kernel)
     if (NT == 4) return launch_msckf_n60(f, a);
+#endif
     g_err = "development build: N = 49..64 only"; return SLK_E_UNSUPPORTED;
 #else
     switch (NT) {
@@ -654,7 +656,7 @@ int slk_update_ekf(slk_filter *f, const double *z, const double *zmean, const do
 #ifdef SLK_STAMPS
     a.dbg = g_dbg;
 #endif
-#ifdef SLK_DEV_N60
+#if defined(SLK_DEV_N60) && !defined(SLK_DEV_EKF)
     g_err = "development build: no EKF kernels"; return SLK_E_UNSUPPORTED;
 #else
     const size_t lds = ekf_tile_lds_doubles(N, m) * sizeof(double);
@@ -664,7 +666,11 @@ int slk_update_ekf(slk_filter *f, const double *z, const double *zmean, const do
         if (rc) return rc;
         hipLaunchKernelGGL(kern, dim3(f->B), dim3(1024), lds, f->stream, a);
     } else {
+#ifdef SLK_DEV_EKF
+        g_err = "development build: EKF tile kernel only"; return SLK_E_UNSUPPORTED;
+#else
         hipLaunchKernelGGL(msckf_ekf_kernel<256>, dim3(f->B), dim3(256), 0, f->stream, a);
+#endif
     }
     HIPCHECK(hipGetLastError());
     return SLK_OK;

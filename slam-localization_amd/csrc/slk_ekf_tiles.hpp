@@ -61,24 +61,43 @@ __device__ __forceinline__ double bcast_lane(double x, int src)
 __device__ __forceinline__ double wave_sum(double x) { return bcast_lane(wave_inclusive_scan(x), 63); }
 
 // Cholesky factor and inverse factor of one 16 x 16 diagonal tile, one wave: lane i (and its three copies) holds row i.
-__device__ __forceinline__ void ekf_diag_factor(double *t, double *dinv, int lane, int row0, int *flag)
+#ifdef SLK_STAMPS
+#define EKF_DF_T(k) do { if (dfdbg) { long long tnow = clock64(); if (lane == 0) dfdbg[k] += tnow - tlast; tlast = tnow; } } while (0)
+#else
+#define EKF_DF_T(k) do { } while (0)
+#endif
+__device__ __forceinline__ void ekf_diag_factor(double *t, double *dinv, int lane, int row0, int *flag, long long *dfdbg = nullptr)
 {
+#ifdef SLK_STAMPS
+    long long tlast = clock64();
+#endif
     const int i = lane & 15;
     double a[16], rsv[16];
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) a[cc] = t[cc * ET + i];
+    double dg = t[i * ET + i];                 // running diagonal element of the own row: its update needs no broadcast
     int fail = -1;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const double d = bcast_lane(a[j], j);
+        const double d = bcast_lane(dg, j);
         if (!(d > 0.0) && fail < 0) fail = row0 + j;
-        double sq, rs;
-        rsqrt_pivot(d, sq, rs);
+        // sqrt(d) and 1 / sqrt(d) by two coupled Goldschmidt steps (two dependent operations each)
+        double g0 = __builtin_amdgcn_rsq(d), h0 = 0.5 * g0;
+        g0 = d * g0;
+        double r0 = fma(-g0, h0, 0.5);
+        g0 = fma(g0, r0, g0);
+        h0 = fma(h0, r0, h0);
+        r0 = fma(-g0, h0, 0.5);
+        g0 = fma(g0, r0, g0);
+        h0 = fma(h0, r0, h0);
+        const double rs = h0 + h0;
         rsv[j] = rs;
-        const double l = (i > j) ? a[j] * rs : (i == j ? sq : 0.0);
+        const double mlt = a[j] * rs;          // the multiplier of every row below the pivot
+        dg = fma(-mlt, mlt, dg);
+        const double l = (i > j) ? mlt : (i == j ? g0 : 0.0);
         a[j] = l;
 #pragma unroll
-        for (int cc = j + 1; cc < 16; ++cc) a[cc] = fma(-l, bcast_lane(l, cc), a[cc]);
+        for (int cc = j + 1; cc < 16; ++cc) a[cc] = fma(-l, bcast_lane(mlt, cc), a[cc]);
     }
     if (lane < 16) {
 #pragma unroll
@@ -87,29 +106,37 @@ __device__ __forceinline__ void ekf_diag_factor(double *t, double *dinv, int lan
         if (lane == 0 && fail >= 0 && *flag < 0) *flag = fail;
     }
     wave_sync();
-    // column i of the inverse: x_i = 1 / l_ii, x_r = -(sum_{p < r} l_rp x_p) / l_rr (l_rp: broadcast reads of the tile)
+    EKF_DF_T(20);
+    // column i of the inverse: x_i = 1 / l_ii, x_r = -(sum_{p < r} l_rp x_p) / l_rr (l_rp: broadcast reads of the tile);
+    // the terms with p < r - 1 do not wait for x_{r-1}: two dependent operations per row
     double x[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        double s = 0.0;
+        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-        for (int p = 0; p < r; ++p) s = fma(t[p * ET + r], x[p], s);
-        x[r] = (r == i) ? rsv[r] : (r > i ? -s * rsv[r] : 0.0);
+        for (int p = 0; p + 1 < r; ++p) {
+            if (p & 1) s1 = fma(t[p * ET + r], x[p], s1);
+            else s0 = fma(t[p * ET + r], x[p], s0);
+        }
+        double sr = s0 + s1;
+        if (r >= 1) sr = fma(t[(r - 1) * ET + r], x[r - 1], sr);
+        x[r] = (r == i) ? rsv[r] : (r > i ? -sr * rsv[r] : 0.0);
     }
     if (lane < 16) {
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) dinv[i * ET + cc] = x[cc];
     }
+    EKF_DF_T(21);
 }
 
 // Blocked Cholesky of the lower-triangle tiles T[ekf_lt(I, J)], NT x NT tiles (padding rows carry a unit diagonal), by
 // all NW waves.  Dinv[J] = inverse of the J-th diagonal factor tile.  The factor overwrites T (strict upper parts of
 // the diagonal tiles are garbage).  *flag = first non-positive pivot, or stays -1.
 template <int NW>
-__device__ __forceinline__ void ekf_tile_cholesky(double *T, double *Dinv, int NT, int wave, int lane, int *flag)
+__device__ __forceinline__ void ekf_tile_cholesky(double *T, double *Dinv, int NT, int wave, int lane, int *flag, long long *dfdbg = nullptr)
 {
     const int c = lane & 15, g = lane >> 4;
-    if (wave == 0) ekf_diag_factor(T, Dinv, lane, 0, flag);
+    if (wave == 0) ekf_diag_factor(T, Dinv, lane, 0, flag, dfdbg);
     __syncthreads();
     for (int J = 0; J + 1 < NT; ++J) {
         const double *Dj = Dinv + J * ETS;
@@ -137,7 +164,7 @@ __device__ __forceinline__ void ekf_tile_cholesky(double *T, double *Dinv, int N
             tstore(tt, c, g, acc);
             if (t == 0) {                                         // the next diagonal tile: factor it straight away
                 wave_sync();
-                ekf_diag_factor(tt, Dinv + (J + 1) * ETS, lane, 16 * (J + 1), flag);
+                ekf_diag_factor(tt, Dinv + (J + 1) * ETS, lane, 16 * (J + 1), flag, dfdbg);
             }
         }
         __syncthreads();
@@ -174,11 +201,17 @@ __device__ __forceinline__ void ekf_block_forward(const double *T, const double 
 __host__ __device__ inline size_t ekf_tile_lds_doubles(int N, int m)
 {
     const int NTR = (m + 15) / 16, NTN = (N + 15) / 16;
-    const size_t gate = (size_t)(NTR * (NTR + 1) / 2 + NTN * NTR) * ETS;                         // S0 tiles + P H^T tiles
+    const int t0 = (NTR * (NTR + 1) / 2 > NTN * NTN) ? NTR * (NTR + 1) / 2 : NTN * NTN;          // S0 tiles (P staged there first)
+    const size_t gate = (size_t)(t0 + NTN * NTR) * ETS;                                          // + P H^T tiles
     const size_t qr = (size_t)(NTR * NTN + NTN * (NTN + 1) / 2 * 2 + NTN + 1 + NTN) * ETS + 256;  // Hq, Hr, Rn/S, T, G, W/Z + v
     return gate > qr ? gate : qr;
 }
 
+#ifdef SLK_STAMPS
+#define EKF_DFDBG (a.dbg ? a.dbg + (size_t)blockIdx.x * 32 : nullptr)
+#else
+#define EKF_DFDBG nullptr
+#endif
 template <int NTHREADS>
 __global__ __launch_bounds__(NTHREADS) void msckf_ekf_tile_kernel(EkfArgs a)
 {
@@ -199,61 +232,72 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_tile_kernel(EkfArgs a)
 
     // ---- gate phase carve
     double *T0 = lds;                                             // lower tiles of S0 -> its factor
-    double *Wt = lds + (size_t)(NTR * (NTR + 1) / 2) * ETS;       // P H^T, tile (pt, J) at J * NTN + pt
+    double *Wt = lds + (size_t)((NTR * (NTR + 1) / 2 > NTN * NTN) ? NTR * (NTR + 1) / 2 : NTN * NTN) * ETS;   // P H^T, tile (pt, J) at J * NTN + pt
     double *Dinv = Wt;                                            // (P H^T is dead once S0 stands)
     if (tid == 0) { sh[0] = m; sh[2] = -1; sh[3] = -1; a.outliers[b] = 0u; }
     EKF_STAMP(0);
     for (int r = tid; r < m; r += NTHREADS) { innov[r] = z[r] - zm[r]; idx[r] = r; }              // :312
     if (tid < 64) tau[tid] = 0.0;
-    for (int t = wave; t < NTN * NTR; t += NW) {                  // W = P H^T  (:765)
-        const int pt = t % NTN, J = t / NTN;
-        const int i = 16 * pt + c, j = 16 * J + c;
-        double af[16], bf[16];
+    // S0 = H P H^T + R (:765-766).  P is staged once as tiles (in the S0 region, free until the second product), every
+    // fragment of H is fetched from global memory once per product and reused across the tiles of its row / column.
+    double *Pt = T0;                                              // tile (I, J) of P at J * NTN + I
+    for (int e = tid; e < NTN * NTN * 256; e += NTHREADS) {
+        const int til = e >> 8, r = e & 15, cc = (e >> 4) & 15, i = 16 * (til % NTN) + r, j = 16 * (til / NTN) + cc;
+        Pt[(size_t)til * ETS + cc * ET + r] = (i < N && j < N) ? P[i + (size_t)N * j] : 0.0;
+    }
+    __syncthreads();
+    for (int it = wave; it < 2 * NTR; it += NW) {                 // W = P H^T: column tile J of W, two row tiles per item
+        const int J = it >> 1, j = 16 * J + c;
+        double bf[16];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const int p = 4 * ks + g;
-            af[ks] = (i < N && p < N) ? P[i + (size_t)N * p] : 0.0;
             bf[ks] = (j < m && p < N) ? H[j + (size_t)m * p] : 0.0;
         }
-        d4 acc = {0.0, 0.0, 0.0, 0.0}, acc1 = acc;
+        for (int pt = (it & 1) * ((NTN + 1) >> 1); pt < ((it & 1) ? NTN : ((NTN + 1) >> 1)); ++pt) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0}, acc1 = acc;
 #pragma unroll
-        for (int ks = 0; ks < 16; ks += 2) {
-            if (4 * ks < N) { acc = ekf_mfma(af[ks], bf[ks], acc); acc1 = ekf_mfma(af[ks + 1], bf[ks + 1], acc1); }
+            for (int ks = 0; ks < 16; ks += 2) {
+                if (4 * ks < N) {
+                    const double *ptile = Pt + (size_t)((ks >> 2) * NTN + pt) * ETS;
+                    acc = ekf_mfma(tfA(ptile, ks & 3, c, g), bf[ks], acc);
+                    acc1 = ekf_mfma(tfA(ptile, (ks + 1) & 3, c, g), bf[ks + 1], acc1);
+                }
+            }
+            tstore(Wt + (size_t)(J * NTN + pt) * ETS, c, g, acc + acc1);
         }
-        tstore(Wt + (size_t)(J * NTN + pt) * ETS, c, g, acc + acc1);
     }
     __syncthreads();
-    for (int t = wave; t < NTR * (NTR + 1) / 2; t += NW) {        // S0 = H W + R, lower tiles
-        int I = 0;
-        while ((I + 1) * (I + 2) / 2 <= t) ++I;
-        const int J = t - I * (I + 1) / 2;
-        const int i = 16 * I + c;
+    for (int it = wave; it < 2 * NTR; it += NW) {                 // S0 = H W + R: row I of lower tiles, split in two halves
+        const int I = it >> 1, i = 16 * I + c, nh = (I + 2) >> 1;
         double af[16];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const int p = 4 * ks + g;
             af[ks] = (i < m && p < N) ? H[i + (size_t)m * p] : 0.0;
         }
-        d4 acc = {0.0, 0.0, 0.0, 0.0}, acc1 = acc;
+        for (int J = (it & 1) ? nh : 0; J < ((it & 1) ? I + 1 : nh); ++J) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0}, acc1 = acc;
 #pragma unroll
-        for (int ks = 0; ks < 16; ks += 2) {
-            if (4 * ks < N) {
-                const double *wt = Wt + (size_t)(J * NTN + (ks >> 2)) * ETS;
-                acc = ekf_mfma(af[ks], tfT(wt, ks & 3, c, g), acc);
-                acc1 = ekf_mfma(af[ks + 1], tfT(wt, (ks + 1) & 3, c, g), acc1);
+            for (int ks = 0; ks < 16; ks += 2) {
+                if (4 * ks < N) {
+                    const double *wt = Wt + (size_t)(J * NTN + (ks >> 2)) * ETS;
+                    acc = ekf_mfma(af[ks], tfT(wt, ks & 3, c, g), acc);
+                    acc1 = ekf_mfma(af[ks + 1], tfT(wt, (ks + 1) & 3, c, g), acc1);
+                }
             }
-        }
-        acc = acc + acc1;
+            acc = acc + acc1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * I + g + 4 * r, col = 16 * J + c;
-            acc[r] = (row < m && col < m) ? acc[r] + R[row + (size_t)m * col] : (row == col ? 1.0 : 0.0);
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * I + g + 4 * r, col = 16 * J + c;
+                acc[r] = (row < m && col < m) ? acc[r] + R[row + (size_t)m * col] : (row == col ? 1.0 : 0.0);
+            }
+            tstore(T0 + (size_t)ekf_lt(I, J) * ETS, c, g, acc);
         }
-        tstore(T0 + (size_t)t * ETS, c, g, acc);
     }
     __syncthreads();
     EKF_STAMP(1);
-    ekf_tile_cholesky<NW>(T0, Dinv, NTR, wave, lane, &sh[2]);
+    ekf_tile_cholesky<NW>(T0, Dinv, NTR, wave, lane, &sh[2], EKF_DFDBG);
     EKF_STAMP(2);
     if (sh[2] >= 0) {
         status |= SLK_ST_SINGULAR;              // the reference would invert an indefinite matrix with PartialPivLU
@@ -352,6 +396,12 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_tile_kernel(EkfArgs a)
                 const double v = tfA(t, ks, c, g);
                 return (i > j) ? v : (i == j ? 1.0 : 0.0);
             };
+#ifdef SLK_STAMPS
+            long long tsw = clock64();
+#define EKF_SW_T(k) do { if (a.dbg && tid == 0) { long long tn = clock64(); a.dbg[(size_t)blockIdx.x * 32 + (k)] += tn - tsw; tsw = tn; } } while (0)
+#else
+#define EKF_SW_T(k) do { } while (0)
+#endif
             for (int p = 0; p < NTN; ++p) {
                 const int c0 = 16 * p, nb = (N - c0 < 16) ? N - c0 : 16;
                 const bool own = wave < nb;
@@ -370,10 +420,17 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_tile_kernel(EkfArgs a)
                         double beta, tk, rden;
                         if (tail <= 2.2250738585072014e-308) { tk = 0.0; beta = cc0; rden = 0.0; }
                         else {
-                            beta = sqrt(cc0 * cc0 + tail);
-                            if (cc0 >= 0.0) beta = -beta;
-                            rden = 1.0 / (cc0 - beta);
-                            tk = (beta - cc0) / beta;
+                            // beta = -sign(c0) |x|, tau = (beta - c0) / beta = 1 + |c0| / |x|, 1 / (c0 - beta) =
+                            // sign(c0) / (|c0| + |x|): one reciprocal square root and one reciprocal, Newton-refined
+                            double nrm, rnrm;
+                            rsqrt_pivot(cc0 * cc0 + tail, nrm, rnrm);
+                            const double ac = fabs(cc0), sg = (cc0 >= 0.0) ? 1.0 : -1.0, dd = ac + nrm;
+                            double rr = __builtin_amdgcn_rcp(dd);
+                            rr = rr * fma(-dd, rr, 2.0);
+                            rr = rr * fma(-dd, rr, 2.0);
+                            beta = -sg * nrm;
+                            tk = fma(ac, rnrm, 1.0);
+                            rden = sg * rr;
                         }
                         const double v0 = (lane > kk) ? x0 * rden : (lane == kk ? 1.0 : 0.0), v1 = x1 * rden;
                         vb[lane] = v0;
@@ -393,6 +450,7 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_tile_kernel(EkfArgs a)
                     }
                 }
                 (void)col;
+                EKF_SW_T(22);
                 // ---- compact WY of the panel: G = V^T V (wave 0), W_t = V^T A_t for the trailing column tiles (waves 1..)
                 const int ntrail = NTN - 1 - p;
                 d4 wacc = {0.0, 0.0, 0.0, 0.0};
@@ -413,6 +471,7 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_tile_kernel(EkfArgs a)
                     if (wave == 0) tstore(Gt, c, g, wacc);
                 }
                 __syncthreads();
+                EKF_SW_T(23);
                 if (wave == 0) {
                     // T (upper triangular): column a by back substitution on T^-1 = striu(G) + diag(1 / tau)
                     const int aa = lane & 15;
@@ -432,6 +491,7 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_tile_kernel(EkfArgs a)
                     }
                 }
                 __syncthreads();
+                EKF_SW_T(24);
                 if (wave >= 1 && wave <= ntrail && wave < 4) {             // Z_t = T^T W_t
                     const double *tp = Tp + (size_t)p * ETS;
                     d4 zz = {0.0, 0.0, 0.0, 0.0};
@@ -450,6 +510,7 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_tile_kernel(EkfArgs a)
                     tstore(at, c, g, acc);
                 }
                 __syncthreads();
+                EKF_SW_T(25);
             }
             EKF_STAMP(6);
             // ---- Hr = R factor (upper N x N), then thinQ in place over the reflectors
@@ -632,7 +693,7 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_tile_kernel(EkfArgs a)
             }
             __syncthreads();
             EKF_STAMP(9);
-            ekf_tile_cholesky<NW>(RnT, Dinv2, NTN, wave, lane, &sh[3]);
+            ekf_tile_cholesky<NW>(RnT, Dinv2, NTN, wave, lane, &sh[3], EKF_DFDBG);
             EKF_STAMP(10);
             if (sh[3] >= 0) {
                 status |= SLK_ST_SINGULAR;

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--clones", type=int, default=8)
     ap.add_argument("--meas", type=int, default=128)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
     import torch
     dev = torch.device("cuda")
@@ -54,6 +55,8 @@ def main():
     print(f"Msckf EKF update N={N} m={m} B={B}: {B / (ms * 1e-3):.4g} updates/s, {ms:.3f} ms per launch, "
           f"{fl / 1e6:.2f} Mflop per update -> {fl * B / (ms * 1e-3) / 1e12:.3f} TFLOP/s fp64 "
           f"({100 * fl * B / (ms * 1e-3) / 78.6e12:.2f} % of 78.6), outliers {int(f.outliers().sum())}, status {int((f.status() != 0).sum())}")
+    if args.no_cpu:
+        return
     # CPU oracle, single thread, bounded sample
     import time
     n = min(B, 8)

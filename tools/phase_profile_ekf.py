@@ -10,9 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-NAMES = ["P H^T, S0 (MFMA)", "Cholesky of S0 (m x m)", "inverse factor", "information blocks, gate", "gather rows",
-         "Householder sweep", "thinQ", "Hr, rn, R thinQ, thinQ^T R thinQ", "P Hr^T, S", "Cholesky of S", "K row solves",
-         "Pk update, delta, boxplus"]
+NAMES = ["P H^T, S0 (MFMA)", "Cholesky of S0 (m x m)", "information blocks (L0^-1 by block columns)", "outlier gate",
+         "gather rows", "Householder sweep (panels + WY)", "Hr, thinQ in place", "rn, thinQ^T R thinQ", "U = Hr P, S",
+         "Cholesky of S", "X = Ls^-1 U", "Pk update, delta, boxplus"]
 
 
 def main():
@@ -21,7 +21,7 @@ def main():
     spec = importlib.util.spec_from_file_location("slk_build", os.path.join(ROOT, "slam-localization_amd", "build.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    so = b.build(stamps=True)
+    so = os.path.join(ROOT, sys.argv[sys.argv.index("--lib") + 1]) if "--lib" in sys.argv else b.build(stamps=True)
     from slkpkg import slk
     import scenarios as sc
     lib = slk.load_library(so)
@@ -40,6 +40,11 @@ def main():
     print(f"EKF update N={e['N']} m={m}: median cycles per filter {tot:.0f}")
     for i, n in enumerate(NAMES):
         print(f"  {n:38s} {np.median(d[:, i]):10.0f}  {100 * np.median(d[:, i]) / tot:5.1f} %")
+    if (t[:, 22] > 0).all():
+        print(f"  Householder sweep: panel columns {np.median(t[:, 22]):.0f}, G / W {np.median(t[:, 23]):.0f}, T {np.median(t[:, 24]):.0f}, "
+              f"Z + trailing update {np.median(t[:, 25]):.0f} cycles")
+    if (t[:, 20] > 0).all():
+        print(f"  diagonal tiles (all factorisations of one update): factor {np.median(t[:, 20]):.0f}, inverse {np.median(t[:, 21]):.0f} cycles")
 
 
 if __name__ == "__main__":
