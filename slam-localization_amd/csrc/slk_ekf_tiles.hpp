@@ -396,6 +396,31 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_tile_kernel(EkfArgs a)
                 const double v = tfA(t, ks, c, g);
                 return (i > j) ? v : (i == j ? 1.0 : 0.0);
             };
+            // V_p^T [V_p | column tiles p+1..] (sweep) or V_p^T [Q column tiles p+1..] (thinQ): tile t of the product on
+            // wave t, its row-tile range dealt to four waves (t, t + 4, t + 8, t + 12); the partial tiles meet in LDS
+            // and are added in a fixed order.  Returns the finished tile to waves 0..3.
+            auto wy_products = [&](int p, bool with_g, double *Sc) -> d4 {
+                const int ntrail = NTN - 1 - p, t = wave & 3, part = wave >> 2;
+                const int nt = with_g ? ntrail + 1 : ntrail, ts = with_g ? t : t - 1;      // tiles per part, slot of tile t
+                const int np = (NTN == 1) ? 1 : 4;                                          // (N <= 16: no room for partial tiles)
+                const bool active = t <= ntrail && (with_g || t >= 1) && part < np;
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+                if (active) {
+                    for (int I = p + part; I < NTr; I += np) {
+                        const double *vt = hq(I, p), *bt = hq(I, p + t);
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            const double av = vT(vt, I, p, ks);
+                            acc = ekf_mfma(av, (t == 0) ? av : tfT(bt, ks, c, g), acc);
+                        }
+                    }
+                    if (part) tstore(Sc + (size_t)((part - 1) * nt + ts) * ETS, c, g, acc);
+                }
+                __syncthreads();
+                if (active && part == 0)
+                    for (int q = 1; q < np; ++q) acc = acc + tload(Sc + (size_t)((q - 1) * nt + ts) * ETS, c, g);
+                return acc;
+            };
 #ifdef SLK_STAMPS
             long long tsw = clock64();
 #define EKF_SW_T(k) do { if (a.dbg && tid == 0) { long long tn = clock64(); a.dbg[(size_t)blockIdx.x * 32 + (k)] += tn - tsw; tsw = tn; } } while (0)
@@ -453,37 +478,27 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_tile_kernel(EkfArgs a)
                 EKF_SW_T(22);
                 // ---- compact WY of the panel: G = V^T V (wave 0), W_t = V^T A_t for the trailing column tiles (waves 1..)
                 const int ntrail = NTN - 1 - p;
-                d4 wacc = {0.0, 0.0, 0.0, 0.0};
-                if (wave <= ntrail && wave < 4) {
-                    d4 w1 = wacc;
-                    for (int I = p; I < NTr; ++I) {
-                        const double *vt = hq(I, p);
-                        const double *bt = (wave == 0) ? vt : hq(I, p + wave);
-#pragma unroll
-                        for (int ks = 0; ks < 4; ks += 2) {
-                            const double a0 = vT(vt, I, p, ks), a1 = vT(vt, I, p, ks + 1);
-                            const double b0 = (wave == 0) ? a0 : tfT(bt, ks, c, g), b1 = (wave == 0) ? a1 : tfT(bt, ks + 1, c, g);
-                            wacc = ekf_mfma(a0, b0, wacc);
-                            w1 = ekf_mfma(a1, b1, w1);
-                        }
-                    }
-                    wacc = wacc + w1;
-                    if (wave == 0) tstore(Gt, c, g, wacc);
-                }
-                __syncthreads();
+                const d4 wacc = wy_products(p, true, HrT);                 // (Hr / Rn regions are free during the sweep)
                 EKF_SW_T(23);
                 if (wave == 0) {
-                    // T (upper triangular): column a by back substitution on T^-1 = striu(G) + diag(1 / tau)
+                    tstore(Gt, c, g, wacc);
+                    wave_sync();
+                    // T (upper triangular): column a by back substitution on T^-1 = striu(G) + diag(1 / tau); the term
+                    // with the element found last is added last (two dependent operations per element)
                     const int aa = lane & 15;
                     double t[16];
 #pragma unroll
                     for (int i = 15; i >= 0; --i) {
-                        double s = 0.0;
+                        double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-                        for (int q = i + 1; q < 16; ++q) s = fma(Gt[q * ET + i], t[q], s);
+                        for (int q = i + 2; q < 16; ++q) {
+                            if (q & 1) s1 = fma(Gt[q * ET + i], t[q], s1);
+                            else s0 = fma(Gt[q * ET + i], t[q], s0);
+                        }
+                        double sr = s0 + s1;
+                        if (i + 1 < 16) sr = fma(Gt[(i + 1) * ET + i], t[i + 1], sr);
                         const double ti = tau[c0 + i];
-                        t[i] = (i == aa) ? ti : -ti * s;
-                        if (i > aa) t[i] = 0.0;
+                        t[i] = (i == aa) ? ti : (i < aa ? -ti * sr : 0.0);
                     }
                     if (lane < 16) {
 #pragma unroll
@@ -535,8 +550,8 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_tile_kernel(EkfArgs a)
                 const int c0 = 16 * p;
                 const int ntrail = NTN - 1 - p;
                 const double *tp = Tp + (size_t)p * ETS;
-                if (wave <= ntrail && wave < 4) {                           // W_t = V_p^T Q_t, Z_t = T W_t
-                    d4 wacc = {0.0, 0.0, 0.0, 0.0};
+                d4 wacc = wy_products(p, false, RnT);                       // W_t = V_p^T Q_t (the Rn region is still free)
+                if (wave <= ntrail && wave < 4) {                           // Z_t = T W_t
                     if (wave == 0) {
                         const double *dt = hq(p, p);                        // V^T E_p = (diagonal tile of V)^T
 #pragma unroll
@@ -544,17 +559,6 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_tile_kernel(EkfArgs a)
                             const int aa = g + 4 * r;
                             wacc[r] = (c0 + c < N) ? ((c > aa) ? dt[aa * ET + c] : (c == aa ? 1.0 : 0.0)) : 0.0;
                         }
-                    } else {
-                        d4 w1 = wacc;
-                        for (int I = p; I < NTr; ++I) {
-                            const double *vt = hq(I, p), *bt = hq(I, p + wave);
-#pragma unroll
-                            for (int ks = 0; ks < 4; ks += 2) {
-                                wacc = ekf_mfma(vT(vt, I, p, ks), tfT(bt, ks, c, g), wacc);
-                                w1 = ekf_mfma(vT(vt, I, p, ks + 1), tfT(bt, ks + 1, c, g), w1);
-                            }
-                        }
-                        wacc = wacc + w1;
                     }
                     d4 zz = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll

@@ -494,6 +494,23 @@ def test_msckf_ekf_update_against_golden_and_oracle(slk, k, m):
         assert rel(Pg[b], r.P) <= TOL and mean_err(lay, Mg[b], r.mean) <= TOL
 
 
+@pytest.mark.parametrize("k,m", [(9, 80), (2, 130), (0, 12), (0, 16)])
+def test_msckf_ekf_update_other_shapes_against_oracle(slk, k, m):
+    # N = 66 > 64 and m = 130 > 128 run the general (global workspace) kernel; N = 12 is the tile kernel's single
+    # column-tile case (m = N: every row survives the compression)
+    e = sc.synthetic_ekf(4, k, m, seed=7100 + k + m)
+    lay = o.layout(o.MULTI, k)
+    f = slk.Msckf(e["mean"], e["P"])
+    f.update_ekf(e["z"], e["zmean"], e["H"], e["R"], gate=(m > 16))
+    Pg, Mg = f.getPk(), f.muState()
+    for b in range(4):
+        r = o.Msckf(k, e["mean"][b], e["P"][b])
+        st, no = r.update_ekf(e["z"][b], e["zmean"][b], e["H"][b], e["R"][b], gate=(m > 16))
+        assert st == f.status()[b] and no == f.outliers()[b]
+        if st == 0:
+            assert rel(Pg[b], r.P) <= TOL and mean_err(lay, Mg[b], r.mean) <= TOL
+
+
 def test_msckf_ekf_update_edge_cases(slk):
     k, m = 2, 40
     e = sc.synthetic_ekf(4, k, m, seed=515, outliers=False)
