@@ -246,7 +246,7 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
                 HIPCHECK(hipGetLastError());
                 s.do_predict = 0;                   // the step kernel takes the predicted state from memory
             }
-            hipLaunchKernelGGL((msckf_chol_kernel<NT, KST>), dim3(s.B), dim3(256), chol_kernel_lds<NT>(s.lay.N), st, s);
+            hipLaunchKernelGGL((msckf_chol_kernel<NT, KST>), dim3(s.B), dim3(64), 0, st, s);
             HIPCHECK(hipGetLastError());
             hipLaunchKernelGGL(kern, dim3(s.B), dim3(NTHREADS), lds, st, s);
             HIPCHECK(hipGetLastError());

@@ -496,10 +496,11 @@ struct CholMCols {
                     double frag[NT];
 #pragma unroll
                     for (int I = JK; I < NT; ++I) {
-                        const double x0 = v[I][0] * r0;
-                        const double x1 = fma(-x0, l10, v[I][1]) * r1;
-                        const double x2 = fma(-x1, l21, fma(-x0, l20, v[I][2])) * r2;
-                        const double x3 = fma(-x2, l32, fma(-x1, l31, fma(-x0, l30, v[I][3]))) * r3;
+                        const double vi0 = v[I][0], vi1 = v[I][1], vi2 = v[I][2], vi3 = v[I][3];
+                        const double x0 = vi0 * r0;
+                        const double x1 = fma(-x0, l10, vi1) * r1;
+                        const double x2 = fma(-x1, l21, fma(-x0, l20, vi2)) * r2;
+                        const double x3 = fma(-x2, l32, fma(-x1, l31, fma(-x0, l30, vi3))) * r3;
                         double f = (g == 0) ? x0 : (g == 1) ? x1 : (g == 2) ? x2 : x3;
                         const int rho = 16 * I + c;
                         if (rho == kap) f = sg;
@@ -1335,18 +1336,20 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
     const double *u = a.u ? a.u + (size_t)bidx * a.u_stride : nullptr;
     if (tid < 25) {
         Sig s = sig_of(tid);
-        double v[12], x[13], y[13];
+        double v[12], x[13];                  // (every loop over them unrolled: registers, no scratch memory)
+#pragma unroll
         for (int t = 0; t < 12; ++t) v[t] = pert(Lblk, 12, nullptr, t, s);
         state_boxplus(x13, v, x);
+        double *yo = Ys + tid * 13;           // f(X_i) goes straight to its LDS row
         if (a.emit == 1) {
+#pragma unroll
             for (int c = 0; c < 13; ++c) a.Xout[((size_t)bidx * 25 + tid) * 13 + c] = x[c];
         } else if (a.pm == SLK_MODEL_EXTERNAL) {
-            for (int c = 0; c < 13; ++c) y[c] = a.Yext[((size_t)bidx * 25 + tid) * 13 + c];
+#pragma unroll
+            for (int c = 0; c < 13; ++c) yo[c] = a.Yext[((size_t)bidx * 25 + tid) * 13 + c];
         } else {
-            process_model(a.pm, u, x, y);
+            process_model(a.pm, u, x, yo);
         }
-        if (a.emit != 1)
-            for (int c = 0; c < 13; ++c) Ys[tid * 13 + c] = y[c];
     }
     if (a.emit == 1) return -1;   // sigma points emitted, nothing else to do
     wave_sync();
@@ -1584,8 +1587,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
         // ---- sigma points of the full state: Msckf.hpp:228-229 -> :400-431
         int fail;
         if constexpr (WCHOL) {
-            // the factor comes from msckf_chol_kernel (its own launch: a latency-bound phase that holds little LDS and
-            // few registers, run there at twice the residency this kernel can have), packed, L2-resident
+            // the factor comes from msckf_chol_kernel (its own launch, one wave per filter at twelve filters per CU),
+            // packed, through a workspace
             const double *gL = a.wsL + (size_t)bidx * pk_size(N);
             for (int e = tid; e < pk_size(N); e += NTHREADS) Lp[e] = gL[e];
             fail = a.wsfail[bidx];
@@ -2447,34 +2450,27 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
 }
 
 // ------------------------------------------------------------------ the Msckf factor kernel
-// generateSigmaPoints' Cholesky of the full covariance (Msckf.hpp:407-413, Eigen::LLT) for 32 < N <= 64: the four-wave
-// blocked factorisation on the fp64 matrix cores (cholw_factor), one workgroup per filter.  A chain of 15 short steps
-// with two barriers each: its throughput comes from workgroups per CU, and on its own it needs 15 KB of LDS and ~64
-// registers -- so it runs here at up to twice the residency of the step kernel (38 KB, 128 registers), and hands the
-// packed factor over through a workspace that stays in L2 / Infinity Cache.
-#ifndef SLK_CHOL_WAVES
-#define SLK_CHOL_WAVES 6
+// generateSigmaPoints' Cholesky of the full covariance (Msckf.hpp:407-413, Eigen::LLT) for 32 < N <= 64, in its own
+// launch: ONE wave per filter (cholm_factor: all ten tiles in registers, no workgroup barrier, 2 KB of LDS, 168
+// registers -> three waves per SIMD), the packed factor handed to the step kernel through a workspace.  Every wave runs
+// the whole 15-step chain on its own and the chip holds twelve filters per CU; measured 45.7 us per 4096 filters against
+// 68 us for the four-waves-per-filter version (two barriers per step, six workgroups per CU): the launch moves 150 MB
+// (P in, L out) at 3.3 TB/s, i.e. it is close to the HBM roof rather than latency-bound.  Fusing the predict chain into
+// the same wave, and a 128-register build at four waves per SIMD, measured the same step time.
+#ifndef SLK_CHOL1_WAVES
+#define SLK_CHOL1_WAVES 3
 #endif
 template <int NT, int KST = -1>
-__global__ __launch_bounds__(256, SLK_CHOL_WAVES) void msckf_chol_kernel(KArgs a)
+__global__ __launch_bounds__(64, SLK_CHOL1_WAVES) void msckf_chol_kernel(KArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) double colbuf[CholM<NT>::COLBUF];
+    const int bidx = blockIdx.x, lane = threadIdx.x;
     const int N = (KST >= 0) ? 12 + 6 * KST : a.lay.N;
-    const int PS = round_up(pk_size(N), 2);
-    double *Lp = smem, *colbuf = smem + PS, *coef = colbuf + CholM<NT>::COLBUF;
-    int *flag = reinterpret_cast<int *>(coef + 16);
     const double *gP = a.P + (size_t)bidx * N * N;
-    d4 acc[NT];
-    cholw_load<NT>(acc, N, lane, wave, [&](int i, int j) { return gP[i + (size_t)j * N]; });
-    const int fail = cholw_factor<NT>(acc, Lp, N, colbuf, coef, lane, wave, flag);
-    double *gL = a.wsL + (size_t)bidx * pk_size(N);
-    for (int e = tid; e < pk_size(N); e += 256) gL[e] = Lp[e];
-    if (tid == 0) a.wsfail[bidx] = fail;
-}
-template <int NT> __host__ inline size_t chol_kernel_lds(int N)
-{
-    return (size_t)(round_up(pk_size(N), 2) + CholM<NT>::COLBUF + 16 + 2) * sizeof(double);
+    d4 acc[CholM<NT>::NTL];
+    cholm_load<NT>(acc, N, lane, [&](int i, int j) { return gP[i + (size_t)j * N]; });
+    const int fail = cholm_factor<NT>(acc, a.wsL + (size_t)bidx * pk_size(N), N, colbuf, lane);
+    if (lane == 0) a.wsfail[bidx] = fail;
 }
 
 // ------------------------------------------------------------------ the Msckf predict kernel

@@ -41,12 +41,12 @@ __device__ __forceinline__ void qrot(const Quat &q, double vx, double vy, double
 // this series for tiny x (3 terms below eps^(1/4)).  Larger arguments take the libm route.
 // The libm routes are rare (rotations beyond the series' domain) and register-hungry: kept out of line so that
 // their temporaries and polynomial constants do not count against the callers' register budget.
-__device__ __attribute__((noinline)) void cos_sinc_sqrt_libm(double x, double *c, double *s)
+// (results by value: a local whose address goes to an out-of-line function would live in scratch memory)
+struct CosSinc { double c, s; };
+__device__ __attribute__((noinline)) CosSinc cos_sinc_sqrt_libm(double x)
 {
-    double sx = sqrt(x), sn, cs;
-    sincos(sx, &sn, &cs);
-    *c = cs;
-    *s = sn / sx;
+    const double sx = sqrt(x);
+    return CosSinc{cos(sx), sin(sx) / sx};
 }
 __device__ __attribute__((noinline)) double so3_log_scale_libm(double n2, double w)
 {
@@ -78,7 +78,9 @@ __device__ __forceinline__ void cos_sinc_sqrt(double x, double &c, double &s)
         c = cc;
         s = ss;
     } else {
-        cos_sinc_sqrt_libm(x, &c, &s);
+        const CosSinc r = cos_sinc_sqrt_libm(x);
+        c = r.c;
+        s = r.s;
     }
 }
 
@@ -186,26 +188,30 @@ __device__ __forceinline__ void dead_reckon_delta(const double *u, double *d)
 // SLK_PM_DEAD_RECKON:    src/core/DeadReckon.hpp:129-239 feeding the delta-pose model; u = dt v0[3] w0[3] v1[3] w1[3]
 __device__ __forceinline__ void process_model(int model, const double *u, const double *x, double *y)
 {
-    double dr[13];
+    double uu[13];              // the inputs in registers (a pointer that may address either global memory or a local
+                                // array would force the array into scratch memory)
     if (model == 3) {           // SLK_PM_DEAD_RECKON: the delta pose comes from the velocity samples
-        dead_reckon_delta(u, dr);
-        u = dr;
+        dead_reckon_delta(u, uu);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) uu[i] = (model == 1 && i > 6) ? 0.0 : u[i];
     }
+    u = nullptr;
     if (model == 1) {
-        double dt = u[6];
-        Quat rot = so3_exp(u[3] * dt, u[4] * dt, u[5] * dt);
+        double dt = uu[6];
+        Quat rot = so3_exp(uu[3] * dt, uu[4] * dt, uu[5] * dt);
         stq(y + 3, qmul(ldq(x + 3), rot));
-        y[10] = u[3]; y[11] = u[4]; y[12] = u[5];
-        y[7] = u[0]; y[8] = u[1]; y[9] = u[2];
+        y[10] = uu[3]; y[11] = uu[4]; y[12] = uu[5];
+        y[7] = uu[0]; y[8] = uu[1]; y[9] = uu[2];
         y[0] = x[0] + x[7] * dt; y[1] = x[1] + x[8] * dt; y[2] = x[2] + x[9] * dt;
     } else {
-        Quat q = qmul(ldq(x + 3), ldq(u + 3));
+        Quat q = qmul(ldq(x + 3), ldq(uu + 3));
         stq(y + 3, q);
-        y[10] = u[10]; y[11] = u[11]; y[12] = u[12];
+        y[10] = uu[10]; y[11] = uu[11]; y[12] = uu[12];
         double rx, ry, rz;
-        qrot(q, u[0], u[1], u[2], rx, ry, rz);
+        qrot(q, uu[0], uu[1], uu[2], rx, ry, rz);
         y[0] = x[0] + rx; y[1] = x[1] + ry; y[2] = x[2] + rz;
-        y[7] = u[7]; y[8] = u[8]; y[9] = u[9];
+        y[7] = uu[7]; y[8] = uu[8]; y[9] = uu[9];
     }
 }
 
