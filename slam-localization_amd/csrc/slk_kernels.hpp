@@ -1999,10 +1999,25 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 if (!(norm > 1e-6 && ++it < 10000)) {
                     // The loop leaves with |mean_delta| <= 1e-6 (:511): the deviations against the final mean follow from the
                     // ones just taken by a first-order correction (below, error O(|mean_delta|^2) <= 1e-12) -- the odd / even
-                    // rebuild applies it while it pairs the items, the other rebuilds take one more full pass.
-                    if (oe_rebuild && it < 10000) break;
+                    // rebuild applies it while it pairs the items, the other shapes in a pass of their own.
+                    if (it < 10000) break;
                     final_pass = true;
                 }
+            }
+            if (!oe_rebuild && it < 10000) {
+                // the same correction for the shapes without the odd / even rebuild, in place (formula: see below)
+                for (int w = tid; w < W; w += NTHREADS) {
+                    const int to = ((unsigned)a.rtab[w] >> 20) & 0xff;
+                    const double m0 = md[to], m1 = md[to + 1], m2 = md[to + 2];
+                    const double x = DR[3 * w], y = DR[3 * w + 1], z = DR[3 * w + 2];
+                    const double cx = y * m2 - z * m1, cy = z * m0 - x * m2, cz = x * m1 - y * m0;      // d x m
+                    const double ax = y * cz - z * cy, ay = z * cx - x * cz, az = x * cy - y * cx;      // d x (d x m)
+                    const double a12 = 1.0 / 12.0 + (x * x + y * y + z * z) * (1.0 / 720.0);
+                    DR[3 * w] = x - m0 + 0.5 * cx - a12 * ax;
+                    DR[3 * w + 1] = y - m1 + 0.5 * cy - a12 * ay;
+                    DR[3 * w + 2] = z - m2 + 0.5 * cz - a12 * az;
+                }
+                __syncthreads();
             }
             if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
             SLK_STAMP(12);
