@@ -277,10 +277,24 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
 // source with run-time sizes.
 static int launch_msckf_n60(slk_filter *f, const KArgs &a)
 {
-    if (a.lay.k == 8 && a.m == 8 && a.do_update && a.emit == 0 && a.rebuild_prec == 0) return launch_msckf_inst<4, 256, 8, 8>(f, a);
+    const bool m8 = a.m == 8 && a.do_update && a.emit == 0 && a.rebuild_prec == 0;
+    if (a.lay.k == 8 && m8) return launch_msckf_inst<4, 256, 8, 8>(f, a);
     if (a.lay.k == 8) return launch_msckf_inst<4, 256, 8>(f, a);
+#ifndef SLK_DEV_N60
+    if (a.lay.k == 7 && m8) return launch_msckf_inst<4, 256, 7, 8>(f, a);       // the window on its way to eight clones
+#endif
     return launch_msckf_inst<4, 256>(f, a);
 }
+#ifndef SLK_DEV_N60
+static int launch_msckf_n48(slk_filter *f, const KArgs &a)                          // N = 36, 42, 48 (k = 4, 5, 6)
+{
+    const bool m8 = a.m == 8 && a.do_update && a.emit == 0 && a.rebuild_prec == 0;
+    if (a.lay.k == 6 && m8) return launch_msckf_inst<3, 256, 6, 8>(f, a);
+    if (a.lay.k == 5 && m8) return launch_msckf_inst<3, 256, 5, 8>(f, a);
+    if (a.lay.k == 4 && m8) return launch_msckf_inst<3, 256, 4, 8>(f, a);
+    return launch_msckf_inst<3, 256>(f, a);
+}
+#endif
 
 static int launch_msckf(slk_filter *f, const KArgs &a0)
 {
@@ -302,7 +316,7 @@ static int launch_msckf(slk_filter *f, const KArgs &a0)
     switch (NT) {
     case 1: return launch_msckf_inst<1, 64>(f, a);
     case 2: return launch_msckf_inst<2, 64>(f, a);
-    case 3: return launch_msckf_inst<3, 256>(f, a);
+    case 3: return launch_msckf_n48(f, a);
     case 4: return launch_msckf_n60(f, a);
     case 5: return launch_msckf_inst<5, 256>(f, a);
     case 6: return launch_msckf_inst<6, 256>(f, a);

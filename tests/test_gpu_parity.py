@@ -77,7 +77,9 @@ def test_msckf_batch_golden_with_outliers(slk):
 @pytest.mark.parametrize("k,m,B", [(0, 2, 96), (1, 2, 96), (3, 6, 64), (8, 8, 64), (10, 8, 8), (12, 8, 16), (13, 8, 6),
                                    (14, 8, 6), (15, 8, 6), (19, 8, 4), (24, 8, 4), (31, 8, 5),
                                    # one tile row per wave (N = 36 .. 60) with fewer than 8 rows: the factor-update path
-                                   (4, 2, 16), (5, 4, 16), (6, 6, 16), (7, 2, 8), (8, 4, 16), (8, 6, 16), (4, 8, 16), (6, 8, 16)])
+                                   (4, 2, 16), (5, 4, 16), (6, 6, 16), (7, 2, 8), (8, 4, 16), (8, 6, 16),
+                                   # exact-shape instantiations (m = 8): k = 4 .. 7
+                                   (4, 8, 16), (5, 8, 16), (6, 8, 16), (7, 8, 16)])
 def test_msckf_step_against_oracle(slk, k, m, B):
     s = sc.synthetic_msckf(B, k, m=m, seed=100 + k)
     lay = o.layout(o.MULTI, k)
