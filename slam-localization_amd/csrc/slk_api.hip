@@ -342,6 +342,36 @@ static int launch_usckf_inst(slk_filter *f, const KArgs &a)
     return SLK_OK;
 }
 
+// N <= 64, plain predict / update / step calls: three launches per step (predict and factorisation as one wave per filter,
+// the update with the covariance left in global memory) -- the fused kernel above keeps the Tier-B modes and N > 64.
+template <int NT>
+static int launch_usckf_split(slk_filter *f, const KArgs &a0)
+{
+    KArgs a = a0;
+    if (a.do_predict) {
+        hipLaunchKernelGGL(usckf_predict_kernel, dim3(a.B), dim3(64), 0, f->stream, a);
+        HIPCHECK(hipGetLastError());
+        if (!a.do_update) return SLK_OK;
+        a.do_predict = 0;
+    }
+    int rc = stage_reserve(f, f->ws_L, (size_t)a.B * pk_size(a.lay.N));
+    if (rc) return rc;
+    rc = stage_reserve(f, f->ws_DR, ((size_t)a.B * sizeof(int) + sizeof(double) - 1) / sizeof(double));
+    if (rc) return rc;
+    a.wsL = f->ws_L.p;
+    a.wsfail = reinterpret_cast<int *>(f->ws_DR.p);
+    hipLaunchKernelGGL((msckf_chol_kernel<NT, -1>), dim3(a.B), dim3(64), 0, f->stream, a);
+    HIPCHECK(hipGetLastError());
+    UCarve cv = carve_usckf(a.lay.N, a.lay.Nq, a.m, NT, true);
+    const size_t lds = (size_t)cv.total * sizeof(double);
+    auto kern = usckf_kernel<NT, 256, true>;
+    rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), f->cfg.device, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(256), lds, f->stream, a);
+    HIPCHECK(hipGetLastError());
+    return SLK_OK;
+}
+
 static int launch_usckf(slk_filter *f, const KArgs &a)
 {
     int NT = (a.lay.N + 15) / 16;
@@ -349,9 +379,10 @@ static int launch_usckf(slk_filter *f, const KArgs &a)
     (void)NT; (void)f; (void)a;
     g_err = "development build: Msckf only"; return SLK_E_UNSUPPORTED;
 #else
+    const bool split = a.emit == 0;
     switch (NT) {
-    case 3: return launch_usckf_inst<3>(f, a);
-    case 4: return launch_usckf_inst<4>(f, a);
+    case 3: return split ? launch_usckf_split<3>(f, a) : launch_usckf_inst<3>(f, a);
+    case 4: return split ? launch_usckf_split<4>(f, a) : launch_usckf_inst<4>(f, a);
     case 5: return launch_usckf_inst<5>(f, a);
     case 6: return launch_usckf_inst<6>(f, a);
     default: g_err = "Usckf state dimension above 96 is not supported by this build"; return SLK_E_UNSUPPORTED;

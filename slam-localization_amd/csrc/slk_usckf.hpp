@@ -9,13 +9,13 @@ namespace slk {
 
 struct UCarve { int P, Lm, mu, small, colbuf, pool, total; int lda, S; };
 
-__host__ __device__ inline UCarve carve_usckf(int N, int Nq, int m, int NT)
+__host__ __device__ inline UCarve carve_usckf(int N, int Nq, int m, int NT, bool split = false)
 {
     UCarve c;
-    c.lda = N | 1;
+    c.lda = split ? N : (N | 1);
     c.S = 2 * N + 1;
     int o = 0;
-    c.P = o;      o += round_up(N * c.lda, 2);
+    c.P = o;      o += split ? 0 : round_up(N * c.lda, 2);     // (split path: the covariance stays in global memory)
     c.Lm = o;     o += round_up(pk_size(N), 2);
     c.mu = o;     o += round_up(Nq, 2);
     c.small = o;  o += 64;
@@ -23,12 +23,15 @@ __host__ __device__ inline UCarve carve_usckf(int N, int Nq, int m, int NT)
     c.pool = o;
     int upd = round_up(c.S * m, 2) + 3 * round_up(N * m, 2) + round_up(m * m, 2) + round_up(m * (m + 1), 2)
               + 4 * round_up(m, 2) + round_up(N, 2);
-    int pred = PRED_SCRATCH + 160 + 160 + 2 * round_up(12 * N, 2);
+    int pred = split ? 0 : PRED_SCRATCH + 160 + 160 + 2 * round_up(12 * N, 2);
     c.total = o + (upd > pred ? upd : pred);
     return c;
 }
 
-template <int NT, int NTHREADS>
+// SPLIT (N <= 64, three launches per step like the Msckf path): predict runs in usckf_predict_kernel, the factorisation in
+// msckf_chol_kernel (one wave per filter each), and this kernel is the update alone: the covariance stays in global
+// memory (its diagonal for the moments, the downdate as a read-modify-write), the factor comes from the workspace.
+template <int NT, int NTHREADS, bool SPLIT = false>
 __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -39,22 +42,24 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
     const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const Lay L = a.lay;
     const int N = L.N, Nq = L.Nq, m = a.m;
-    const UCarve cv = carve_usckf(N, Nq, m, NT);
+    const UCarve cv = carve_usckf(N, Nq, m, NT, SPLIT);
     const int lda = cv.lda, S = cv.S;
-    double *P = smem + cv.P, *Lm = smem + cv.Lm, *mu = smem + cv.mu, *colbuf = smem + cv.colbuf, *pool = smem + cv.pool;
-    int *ish = reinterpret_cast<int *>(smem + cv.small);
     double *gmean = a.mean + (size_t)bidx * Nq;
     double *gP = a.P + (size_t)bidx * N * N;
+    double *P = SPLIT ? gP : smem + cv.P, *Lm = smem + cv.Lm, *mu = smem + cv.mu, *colbuf = smem + cv.colbuf, *pool = smem + cv.pool;
+    int *ish = reinterpret_cast<int *>(smem + cv.small);
     int status = 0;
     if (a.do_update && a.emit != 4 && tid == 0) a.outliers[bidx] = 0u;
     if (tid == 0) ish[42] = 0;
 
+    SLK_STAMP_NR(0);
     for (int e = tid; e < Nq; e += NTHREADS) mu[e] = gmean[e];
-    for (int c = wave; c < N; c += NW)
-        for (int r = lane; r < N; r += 64) P[r + c * lda] = gP[r + (size_t)c * N];
+    if constexpr (!SPLIT)
+        for (int c = wave; c < N; c += NW)
+            for (int r = lane; r < N; r += 64) P[r + c * lda] = gP[r + (size_t)c * N];
     __syncthreads();
 
-    if (a.do_predict || a.emit == 1) {
+    if (!SPLIT && (a.do_predict || a.emit == 1)) {
         // ---- Usckf::predict, Usckf.hpp:107-244
         double *Lblk = pool, *Pn = pool + 160, *Pxy = pool + 320, *Fk = pool + 480, *scr = pool + 640;
         double *RB = pool + 640 + 800;             // old rows 24..35 of P: 12 x N (ld 12)
@@ -127,7 +132,12 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
     if (a.do_update || a.emit == 2) {
         // ---- Usckf::update, Usckf.hpp:246-308
         int fail;
-        if constexpr (NT <= 4) {
+        if constexpr (SPLIT) {
+            const double *gL = a.wsL + (size_t)bidx * pk_size(N);
+            for (int e = tid; e < pk_size(N); e += NTHREADS) Lm[e] = gL[e];
+            fail = a.wsfail[bidx];
+            __syncthreads();
+        } else if constexpr (NT <= 4) {
             if (wave == 0) {
                 d4 acc[CholM<NT>::NTL];
                 cholm_load<NT>(acc, N, lane, [&](int i, int j) { return P[i + j * lda]; });
@@ -140,6 +150,7 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
             fail = chol_packed<NTHREADS, SDN>(Lm, N, colbuf, tid, [&](int i, int j) { return P[i + j * lda]; });
         }
         bool applied = false;
+        SLK_STAMP_NR(3);
         if (fail >= 0) {
             status |= SLK_ST_LLT_FAIL;
         } else if (a.emit == 2) {
@@ -170,6 +181,7 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
             double *dlt = wv + 2 * round_up(m, 2);
             measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lm, Z, DZ, Pxz, Sm, zbar, innov, &ish[42],
                                            [&](int t) { return P[t + t * lda]; });
+            SLK_STAMP_NR(6);
             if (a.emit == 4) {
                 // innovation and its covariance for a caller-side significance test (Usckf.hpp:262-302 with an
                 // arbitrary `mt`): Xout [B][m*m + m] = S (column-major), innovation; nothing else happens
@@ -193,6 +205,7 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
                 if (lane == 0) ish[46] = f0;
             }
             __syncthreads();
+            SLK_STAMP_NR(7);
             const int sfail = ish[46];
             if (a.emit == 4) {
             } else if (sfail >= 0) {
@@ -226,6 +239,7 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
                     ish[40] = ok ? 1 : 0;
                 }
                 __syncthreads();
+                SLK_STAMP_NR(8);
                 if (!ish[40]) {
                     if (tid == 0) a.outliers[bidx] = 1u;
                     status |= SLK_ST_ALL_REJECTED;
@@ -236,13 +250,36 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
                         dlt[t] = sum;
                     }
                     // Pk -= K S K^T (:296); K S = covXZ
-                    for (int j = wave; j < N; j += NW)
-                        for (int i = lane; i < N; i += 64) {
-                            double sum = 0.0;
-                            for (int c = 0; c < m; ++c) sum += Pxz[i + N * c] * K[j + N * c];
-                            P[i + j * lda] -= sum;
+                    if constexpr (SPLIT) {
+                        // read-modify-write of the covariance in global memory: eight elements per thread in flight
+                        for (int e0 = 0; e0 < N * N; e0 += 8 * NTHREADS) {
+                            double pv[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int e = e0 + q * NTHREADS + tid;
+                                pv[q] = (e < N * N) ? P[e] : 0.0;
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int e = e0 + q * NTHREADS + tid;
+                                if (e < N * N) {
+                                    const int i = e % N, j = e / N;
+                                    double sum = 0.0;
+                                    for (int c = 0; c < m; ++c) sum += Pxz[i + N * c] * K[j + N * c];
+                                    P[e] = pv[q] - sum;
+                                }
+                            }
                         }
+                    } else {
+                        for (int j = wave; j < N; j += NW)
+                            for (int i = lane; i < N; i += 64) {
+                                double sum = 0.0;
+                                for (int c = 0; c < m; ++c) sum += Pxz[i + N * c] * K[j + N * c];
+                                P[i + j * lda] -= sum;
+                            }
+                    }
                     __syncthreads();
+                    SLK_STAMP_NR(9);
                     // mu_state = mu_state + state(K * innovation) :299-301 (set() then boxplus through
                     // getVectorizedState(): exp/log round trip == direct boxplus for |rotation| < pi)
                     for (int t = tid; t < N; t += NTHREADS) {
@@ -259,12 +296,76 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
         }
         __syncthreads();
         if (a.emit != 2 && a.emit != 4 && (applied || a.do_predict)) {
-            for (int c = wave; c < N; c += NW)
-                for (int r = lane; r < N; r += 64) gP[r + (size_t)c * N] = P[r + c * lda];
-            for (int e = tid; e < Nq; e += NTHREADS) gmean[e] = mu[e];
+            if constexpr (!SPLIT)
+                for (int c = wave; c < N; c += NW)
+                    for (int r = lane; r < N; r += 64) gP[r + (size_t)c * N] = P[r + c * lda];
+            if (applied || !SPLIT)
+                for (int e = tid; e < Nq; e += NTHREADS) gmean[e] = mu[e];
         }
     }
+    SLK_STAMP_NR(10);
     if (tid == 0 && status) atomicOr(a.status + bidx, status);
+}
+
+// Usckf::predict (Usckf.hpp:107-244) for the split path: one wave per filter, the covariance in global memory.  The
+// 12-DOF prediction of state k+i (predict_phase), Fk = Pxy^T Pk_i^-1 (:154), then the cross blocks: rows of state k+i
+// against everything else Fk * block (:200-208, :221-232), columns against statek / statek_l block * Fk^T (:190-198),
+// feature rows as transposes (:227, :235).  All old values are staged in LDS before the first write.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void usckf_predict_kernel(KArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double sm[16 + 4 * 160 + 736 + 288];
+    const int bidx = blockIdx.x, tid = threadIdx.x;
+    const int N = a.lay.N, Nq = a.lay.Nq;
+    double *mu = sm, *Lblk = sm + 16, *Pn = Lblk + 160, *Pxy = Pn + 160, *Fk = Pxy + 160, *scr = Fk + 160, *CB = scr + 736;
+    double *gmean = a.mean + (size_t)bidx * Nq;
+    double *gP = a.P + (size_t)bidx * N * N;
+    if (tid < 13) mu[tid] = gmean[26 + tid];
+    wave_sync();
+    const int st = predict_phase<true>(a, bidx, tid, [&](int i, int j) { return gP[(24 + i) + (size_t)(24 + j) * N]; },
+                                       Lblk, mu, Pn, scr, Pxy);
+    if (st < 0) return;                              // sigma points emitted
+    if (!(st & SLK_ST_LLT_FAIL)) {
+        if (tid < 12) {                              // Fk^T = Pk_i^-1 Pxy: forward + backward substitution per column
+            double x[12];
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                double s = Pxy[r + 12 * tid];
+#pragma unroll
+                for (int p = 0; p < r; ++p) s -= Lblk[pk(12, r, p)] * x[p];
+                x[r] = s / Lblk[pk(12, r, r)];
+            }
+#pragma unroll
+            for (int r = 11; r >= 0; --r) {
+                double s = x[r];
+#pragma unroll
+                for (int p = r + 1; p < 12; ++p) s -= Lblk[pk(12, p, r)] * x[p];
+                x[r] = s / Lblk[pk(12, r, r)];
+            }
+#pragma unroll
+            for (int r = 0; r < 12; ++r) Fk[tid + 12 * r] = x[r];      // column tid of Fk^T = row tid of Fk
+        }
+        double *RB = scr;                            // old rows 24..35 of P: 12 x N (ld 12); the predict scratch is dead
+        for (int e = tid; e < 12 * N; e += 64) RB[e] = gP[(24 + e % 12) + (size_t)(e / 12) * N];
+        for (int e = tid; e < 24 * 12; e += 64) CB[e] = gP[(e % 24) + (size_t)(24 + e / 24) * N];   // old cols, rows < 24
+        wave_sync();
+        for (int e = tid; e < 12 * N; e += 64) {     // rows of state k+i against everything but itself: Fk * old rows
+            const int r = e % 12, c = e / 12;
+            if (c >= 24 && c < 36) continue;
+            double s = 0.0;
+            for (int p = 0; p < 12; ++p) s += Fk[r + 12 * p] * RB[p + 12 * c];
+            gP[(24 + r) + (size_t)c * N] = s;
+            if (c >= 36) gP[c + (size_t)(24 + r) * N] = s;          // feature rows against state k+i: the transposes
+        }
+        for (int e = tid; e < 24 * 12; e += 64) {    // columns of state k+i against statek and statek_l: old cols * Fk^T
+            const int r = e % 24, c = e / 24;
+            double s = 0.0;
+            for (int p = 0; p < 12; ++p) s += CB[r + 24 * p] * Fk[c + 12 * p];
+            gP[r + (size_t)(24 + c) * N] = s;
+        }
+        for (int e = tid; e < 144; e += 64) gP[(24 + e % 12) + (size_t)(24 + e / 12) * N] = Pn[e];
+        if (tid < 13) gmean[26 + tid] = mu[tid];
+    }
+    if (tid == 0 && st) atomicOr(a.status + bidx, st);
 }
 
 // Usckf::cloning, Usckf.hpp:391-433; one workgroup per filter.  Blocks: 0 statek, 1 statek_l, 2 statek_i
