@@ -379,7 +379,7 @@ static int launch_usckf(slk_filter *f, const KArgs &a)
     (void)NT; (void)f; (void)a;
     g_err = "development build: Msckf only"; return SLK_E_UNSUPPORTED;
 #else
-    const bool split = a.emit == 0;
+    const bool split = a.emit == 0 && a.lay.N <= 60;       // (usckf_predict_kernel stages 12 x N old rows in 736 doubles)
     switch (NT) {
     case 3: return split ? launch_usckf_split<3>(f, a) : launch_usckf_inst<3>(f, a);
     case 4: return split ? launch_usckf_split<4>(f, a) : launch_usckf_inst<4>(f, a);

@@ -285,6 +285,26 @@ def test_usckf_spd_predict_update_against_golden_and_oracle(slk):
     np.testing.assert_array_equal(h.muState(), M)
 
 
+@pytest.mark.parametrize("nfk,nfkl", [(3, 0), (3, 18), (3, 23)])
+def test_usckf_other_feature_counts_against_oracle(slk, nfk, nfkl):
+    # N = 39 and 57 take the three-launch path (predict / factor / update), N = 62 the fused kernel
+    s = sc.synthetic_usckf(3, nfk=nfk, nfkl=nfkl, seed=400 + nfkl)
+    lay = o.layout(o.AUGMENTED, 0, nfk, nfkl)
+    f = slk.Usckf(mean=s["mean"], P=s["P"], nfk=nfk, nfkl=nfkl)
+    f.predict(slk.PM_CONST_VELOCITY, s["u"], s["Q"])
+    f.update(s["z"], slk.MM_VO_RELATIVE, None, s["R"])
+    f.step(slk.PM_CONST_VELOCITY, s["u"], s["Q"], s["z"], slk.MM_VO_RELATIVE, None, s["R"])
+    assert (f.status() == 0).all()
+    P, M = f.PkAugmentedState(), f.muState()
+    for b in range(3):
+        g = o.Usckf(nfk=nfk, nfkl=nfkl, mean=s["mean"][b], P=s["P"][b])
+        for _ in range(2):
+            assert g.predict(o.pm_const_velocity(s["u"][b, 0:3], s["u"][b, 3:6], s["u"][b, 6]), s["Q"]) == 0
+            stc, acc = g.update(s["z"][b], o.mm_vo_relative(), s["R"])
+            assert stc == 0 and acc == 1
+        assert rel(P[b], g.P) <= TOL and mean_err(lay, M[b], g.mean) <= TOL
+
+
 def test_usckf_whole_vector_gate_and_other_models(slk):
     # Usckf.hpp:262-302 with a chi-square gate (mt) instead of accept_any: accepted and rejected filters
     s = sc.synthetic_usckf(4, seed=77)
