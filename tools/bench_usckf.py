@@ -15,7 +15,8 @@ def main():
     from slkpkg import slk
     import scenarios as sc
     from oracle import oracle as o
-    for B in (1024, 4096, 16384):
+    batches = [int(x) for x in sys.argv[1:]] or [1024, 4096, 16384]
+    for B in batches:
         s = sc.synthetic_usckf(B)
         f = slk.Usckf(mean=s["mean"], P=s["P"], nfk=3, nfkl=9)
         dev = torch.device("cuda")
