@@ -612,18 +612,23 @@ __global__ __launch_bounds__(NTHREADS) void msckf_ekf_tile_kernel(EkfArgs a)
                     for (int I = 2 * q; I < 2 * q + 2 && I < NTr; ++I) {
                         const int ri = (16 * I + c < mm) ? idx[16 * I + c] : -1;
                         d4 t1 = {0.0, 0.0, 0.0, 0.0}, t1b = t1;
-                        for (int K = 0; K < NTr; ++K) {
-                            const double *qk = hq(K, bt);
-                            double af[4];
+                        for (int K0 = 0; K0 < NTr; K0 += 4) {                  // four tile columns of R' in flight at a time
+                            double af[16];
 #pragma unroll
-                            for (int ks = 0; ks < 4; ++ks) {
-                                const int pp = 16 * K + 4 * ks + g;
-                                af[ks] = (ri >= 0 && pp < mm) ? R[ri + (size_t)m * idx[pp]] : 0.0;
+                            for (int u = 0; u < 16; ++u) {
+                                const int pp = 16 * K0 + 4 * u + g;               // (u = 4 (K - K0) + ks)
+                                af[u] = (ri >= 0 && pp < mm) ? R[ri + (size_t)m * idx[pp]] : 0.0;
                             }
 #pragma unroll
-                            for (int ks = 0; ks < 4; ks += 2) {
-                                t1 = ekf_mfma(af[ks], tfT(qk, ks, c, g), t1);
-                                t1b = ekf_mfma(af[ks + 1], tfT(qk, ks + 1, c, g), t1b);
+                            for (int kq = 0; kq < 4; ++kq) {
+                                if (K0 + kq < NTr) {
+                                    const double *qk = hq(K0 + kq, bt);
+#pragma unroll
+                                    for (int ks = 0; ks < 4; ks += 2) {
+                                        t1 = ekf_mfma(af[4 * kq + ks], tfT(qk, ks, c, g), t1);
+                                        t1b = ekf_mfma(af[4 * kq + ks + 1], tfT(qk, ks + 1, c, g), t1b);
+                                    }
+                                }
                             }
                         }
                         t1 = t1 + t1b;
