@@ -149,6 +149,10 @@ struct Carve {
 __host__ __device__ inline int z_region(int S, int m, int NT, bool big)
 {
     const int z = round_up(S * m, 2);
+    if (big && m <= 8) {             // factor_update_blocks: W [N][8] + wave totals [8][36] after the moments
+        const int w = 8 * ((S - 1) / 2) + 8 * 36 + 8;
+        return z > w ? z : w;
+    }
     return (!big && NT >= 3 && NT <= 4 && m <= 8 && z < 512) ? 512 : z;
 }
 
@@ -825,9 +829,11 @@ __device__ __forceinline__ void ldm_prefix(const double (&a)[8], double (&Gf)[36
 // column-major), kept = bit mask of the rows that survived the gate.  Writes Wbuf[j][:] = 1/2 w~_j (the factor 1/2 of
 // a_i = 1/2 dZ_i is folded in here, so that the product can read dZ as it stands) and mdiag[j] = sqrt(d_j).
 // Returns false if Pk - K S K^T is not positive definite (uniform over the wave).
+template <bool FLAT = false>
 __device__ __forceinline__ bool ldm_columns(double (&Gf)[36], const double (&a)[8], const double *Sm, int m, unsigned kept,
                                             int lane, int N, double *Wbuf, double *mdiag)
 {
+    // FLAT: `lane` is the column index of a multi-wave caller (factor_update_blocks), Wbuf is [N][8]
     const bool live = lane < N;
     double b[8];
 #pragma unroll
@@ -878,13 +884,123 @@ __device__ __forceinline__ bool ldm_columns(double (&Gf)[36], const double (&a)[
 #pragma unroll
         for (int p = c + 1; p < 8; ++p) s = fma(-SLK_G(p, c), y[p], s);
         y[c] = s * SLK_G(c, c);
-        Wbuf[bw_idx(lane, c)] = live ? y[c] * sc : 0.0;
+        if (FLAT) { if (live) Wbuf[lane * 8 + c] = y[c] * sc; }
+        else Wbuf[bw_idx(lane, c)] = live ? y[c] * sc : 0.0;
     }
     if (live) mdiag[lane] = sqd;
     // (lanes beyond N carry a = 0 and the full prefix: d = 1, they never fail the test unless the real columns do)
     return __all(ok) != 0;
 }
 #undef SLK_G
+
+// The same factor update for states beyond one wave of columns (N > 64), in O(N^2 m) instead of the O(N^3) factorisation
+// of Pk - K S K^T.  With M_jj = sqrt(d_j), M_ij = dZ_i . W_j (i > j) and the columns in blocks of 16:
+//     L'(:, J) = L(:, J) M_JJ + U_J W_J^T,   U_J = sum over the column blocks right of J of L(:, J') dZ_J'  (N x 8),
+// so a tile row of the factor is a recurrence of its own over its column blocks, right to left, ten MFMAs per tile:
+// (L_IJ M_JJ)^T = M_JJ^T L_IJ^T (4), + W_J U^T (2), U^T += dZ_J^T L_IJ^T (4) -- all three take the SAME fragment of the
+// factor tile as their B operand, and U^T stays in the accumulator layout the second product reads it in.
+// Thread j owns column j for the prefix sums (per-wave scan + wave totals through LDS) and its 8 x 8 Schur matrix
+// (ldm_columns); the M_JJ tiles come from 2 MFMAs each.  scratch: Wb [N][8], totals [NTHREADS / 64][36], Mt [ntc][16 x 17].
+// Lp may be the global workspace.  Returns false if Pk - K S K^T is not positive definite.
+template <int NTHREADS>
+__device__ __forceinline__ bool factor_update_blocks(double *Lp, int N, const double *DZ, int m, const double *Sm, unsigned kept,
+                                                     double *Wb, double *mdiag, double *totals, double *Mt, int *flag, int tid)
+{
+    constexpr int NW = NTHREADS / 64;
+    const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int ntc = (N + 15) >> 4;
+    {
+        double av[8], Gf[36];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            const bool in = tid < N && cc < m;
+            const double dz = DZ[in ? tid * m + cc : 0];
+            av[cc] = in ? 0.5 * dz : 0.0;
+        }
+        ldm_prefix(av, Gf);
+        if (lane == 63) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int cc = 0; cc <= r; ++cc) totals[wave * 36 + r * (r + 1) / 2 + cc] = Gf[r * (r + 1) / 2 + cc] + av[r] * av[cc];
+        }
+        if (tid == 0) *flag = 1;
+        __syncthreads();
+        for (int w = 0; w < wave; ++w)
+#pragma unroll
+            for (int e = 0; e < 36; ++e) Gf[e] += totals[w * 36 + e];
+        const bool pd = ldm_columns<true>(Gf, av, Sm, m, kept, tid, N, Wb, mdiag);
+        if (!pd && lane == 0) *flag = 0;
+    }
+    __syncthreads();
+    if (*flag == 0) return false;
+    // M_JJ tiles: element (i, j) at i * 17 + j
+    for (int J = wave; J < ntc; J += NW) {
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int i = 16 * J + c, cc = 4 * ks + g;
+            const double av = (i < N && cc < m) ? DZ[i * m + cc] : 0.0;       // A[row i][k c']
+            const double bv = (i < N) ? Wb[i * 8 + cc] : 0.0;                 // B[k c'][col j]: lane c = j
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = g + 4 * q, j = c, gi = 16 * J + i;
+            const double v = (i > j) ? acc[q] : ((i == j && gi < N) ? mdiag[gi] : 0.0);
+            Mt[J * 272 + i * 17 + j] = (gi < N && 16 * J + j < N) ? v : 0.0;
+        }
+    }
+    __syncthreads();
+    // tile rows dealt to the waves in a snake over their cost (row I has I + 1 tiles)
+    for (int u0 = 0; u0 < ntc; u0 += 2 * NW) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int u = half ? u0 + 2 * NW - 1 - wave : u0 + wave;
+            const int I = ntc - 1 - u;
+            if (u >= ntc || I < 0) continue;
+            const int row = 16 * I + c;
+            d4 UT = {0.0, 0.0, 0.0, 0.0};
+            double lf[4], ln[4];
+            auto fetch = [&](int J, double (&dst)[4]) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int col = 16 * J + 4 * ks + g;
+                    const bool ok = J >= 0 && row < N && col <= row;
+                    dst[ks] = ok ? Lp[pk(N, ok ? row : 0, ok ? col : 0)] : 0.0;
+                }
+            };
+            fetch(I, lf);
+            for (int J = I; J >= 0; --J) {
+                fetch(J - 1, ln);                                   // the next tile while this one is worked on
+                const double *mt = Mt + J * 272;
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)                      // (L_IJ M_JJ)^T: A[row j][k i] = M_JJ(i, j)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(mt[(4 * ks + g) * 17 + c], lf[ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {                    // + W_J U^T: A[row j][k c'] = W(16J + j, c')
+                    const int j = 16 * J + c;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64((j < N) ? Wb[j * 8 + 4 * ks + g] : 0.0, UT[ks], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {                    // U^T += dZ_J^T L_IJ^T: A[row c'][k i] = dZ(16J + i, c')
+                    const int i = 16 * J + 4 * ks + g;
+                    UT = __builtin_amdgcn_mfma_f64_16x16x4f64((i < N && c < m) ? DZ[i * m + c] : 0.0, lf[ks], UT, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                       // acc: row j = g + 4q of the block, column = factor row
+                    const int col = 16 * J + g + 4 * q;
+                    if (row < N && col <= row) Lp[pk(N, row, col)] = acc[q];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) lf[ks] = ln[ks];
+            }
+        }
+    }
+    __syncthreads();
+    return true;
+}
 
 // output tile (I, J) of the lower triangle -> the wave that computes it; MFMA cost of a tile is 6 (I - J + 1)
 template <int NT> __device__ __forceinline__ constexpr int ldm_tile_wave(int I, int J)
@@ -1906,7 +2022,20 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                         };
                         if constexpr (BIG) {
                             double *panel = innov + 2 * round_up(m, 2);      // behind the measurement arrays
-                            fail = chol_blocked_mem<NTHREADS>(Lp, N, panel, colbuf, &ish[45], tid, down);
+                            // applyDelta's factor as a factor UPDATE by tile rows (factor_update_blocks): O(N^2 m) instead
+                            // of the O(N^3) factorisation of the downdated matrix; needs covXZ = L A (no wrapped rotation
+                            // column), at most eight rows and an SPD innovation covariance.  The gain K (in Z's place) is
+                            // dead once delta stands: Z holds W and the wave totals, the Cholesky panel the M_JJ tiles.
+                            if (m <= 8 && mmr <= 8 && sfail < 0 && ish[42] == 0) {
+                                unsigned kept = 0;
+                                for (int r = 0; r < mmr; ++r) kept |= 1u << idx[r];
+                                __syncthreads();
+                                const bool pd = factor_update_blocks<NTHREADS>(Lp, N, DZ, m, Sm, kept, Z, md, Z + round_up(8 * N, 2),
+                                                                               panel, &ish[44], tid);
+                                fail = pd ? -1 : 0;                          // not positive definite: as a failed LLT
+                            } else {
+                                fail = chol_blocked_mem<NTHREADS>(Lp, N, panel, colbuf, &ish[45], tid, down);
+                            }
                         } else {
                             fail = chol_packed<NTHREADS, SDN>(Lp, N, colbuf, tid, down);
                         }
