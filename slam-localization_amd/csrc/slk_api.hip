@@ -257,10 +257,20 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
     if (BIG) {
         int rc = stage_reserve(f, f->ws_L, (size_t)a.B * pk_size(a.lay.N));
         if (rc) return rc;
-        rc = stage_reserve(f, f->ws_DR, (size_t)a.B * 3 * cv.W);
+        const size_t ndr = (size_t)a.B * 3 * cv.W;                   // rotation deviations, then one int per filter
+        rc = stage_reserve(f, f->ws_DR, ndr + ((size_t)a.B * sizeof(int) + sizeof(double) - 1) / sizeof(double));
         if (rc) return rc;
         a.wsL = f->ws_L.p;
         a.wsDR = f->ws_DR.p;
+        if (a.do_update || a.emit >= 2) {                            // the first factorisation in its own launch
+            a.wsfail = reinterpret_cast<int *>(f->ws_DR.p + ndr);
+            auto ck = msckf_chol_big_kernel<NTHREADS>;
+            const size_t clds = chol_big_lds(a.lay.N);
+            rc = ensure_dynamic_lds(reinterpret_cast<const void *>(ck), f->cfg.device, clds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(ck, dim3(a.B), dim3(NTHREADS), clds, f->stream, a);
+            HIPCHECK(hipGetLastError());
+        }
     }
     size_t lds = (size_t)cv.total * sizeof(double);
     if (lds > 160 * 1024) { g_err = "state too large for the LDS-resident kernel"; return SLK_E_UNSUPPORTED; }

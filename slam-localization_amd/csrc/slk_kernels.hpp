@@ -1719,7 +1719,9 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
             __syncthreads();
             fail = ish[45];
         } else if constexpr (BIG) {
-            fail = chol_blocked_mem<NTHREADS>(Lp, N, pool, colbuf, &ish[45], tid, Pin);
+            // (the launcher ran msckf_chol_big_kernel: the factor is in the workspace already)
+            if (a.wsfail) fail = a.wsfail[bidx];
+            else fail = chol_blocked_mem<NTHREADS>(Lp, N, pool, colbuf, &ish[45], tid, Pin);
         } else {
             fail = chol_packed<NTHREADS, SDN>(Lp, N, colbuf, tid, Pin);
         }
@@ -2616,6 +2618,23 @@ __global__ __launch_bounds__(64, SLK_CHOL1_WAVES) void msckf_chol_kernel(KArgs a
     const int fail = cholm_factor<NT>(acc, a.wsL + (size_t)bidx * pk_size(N), N, colbuf, lane);
     if (lane == 0) a.wsfail[bidx] = fail;
 }
+
+// The large states' first factorisation (N > 80, chol_blocked_mem on the global workspace) in its own launch as well: it
+// needs the 16-column panel and little else in LDS (30 KB against the 90 KB of the step kernel), so several filters of a
+// CU factor side by side -- at B = 512 the step kernel alone ran this latency-bound phase twice in a row on every CU.
+template <int NTHREADS>
+__global__ __launch_bounds__(NTHREADS, 4) void msckf_chol_big_kernel(KArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int flag;
+    const int bidx = blockIdx.x, tid = threadIdx.x, N = a.lay.N;
+    const int TN = 16 * ((N + 15) / 16);
+    const double *gP = a.P + (size_t)bidx * N * N;
+    const int fail = chol_blocked_mem<NTHREADS>(a.wsL + (size_t)bidx * pk_size(N), N, smem, smem + TN * 17, &flag, tid,
+                                                [&](int i, int j) { return gP[i + (size_t)j * N]; });
+    if (tid == 0) a.wsfail[bidx] = fail;
+}
+__host__ inline size_t chol_big_lds(int N) { return (size_t)(16 * ((N + 15) / 16) * 17 + 4 * 34 + 136 + 8) * sizeof(double); }
 
 // ------------------------------------------------------------------ the Msckf predict kernel
 // Msckf::predict (Msckf.hpp:89-189; state <-> clone cross-covariances stay stale, :171-182): sigma points of the current
