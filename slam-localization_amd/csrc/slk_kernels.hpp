@@ -173,7 +173,7 @@ __host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT, bool bi
     c.md = o;     o += round_up(N, 2);
     c.cq = o;     o += 4 * L.nso3;                 // ref_b^-1 * mu_b per SO(3) block (mean loop)
     c.small = o;  o += 96;
-    c.colbuf = o; o += big ? (4 * 34 + 136) : 4 * ((c.TN > 32 ? c.TN : 32) + 2);   // big: cholm<1..2> buffer + packed 16x16 factor
+    c.colbuf = o; o += big ? (4 * 34 + 136 + 16) : 4 * ((c.TN > 32 ? c.TN : 32) + 2);   // big: cholm<1..2> buffer + packed 16x16 factor + its reciprocal pivots
     c.pool = o;
     // measurement part: Z[S*m] (the gain K[N*m] reuses its place once the moments are done) DZ[N*m] Pxz[N*m]
     // Sm[m*m] G[m*(2m+1)] zbar innov
@@ -720,7 +720,20 @@ __device__ __forceinline__ int chol_blocked_mem(double *Lp, int n, double *panel
             }
             const int ra = 16 * I + c, rb = c0 + c;
             const bool oka = ra < n, okb = rb < n;
-            for (int kk = 0; kk < c0; kk += 16) {          // c0 is a multiple of 16: four k-steps per trip, loads first
+            int kk = 0;
+            for (; kk + 32 <= c0; kk += 32) {              // eight k-steps per trip: sixteen loads in flight (the factor may
+                double af[8], bf[8];                        // live in the global workspace: latency, not bandwidth)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int col = kk + 4 * u + g;
+                    const double av = Lp[oka ? pk(n, ra, col) : 0], bv = Lp[okb ? pk(n, rb, col) : 0];
+                    af[u] = oka ? -av : 0.0;
+                    bf[u] = okb ? bv : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u], bf[u], acc, 0, 0, 0);
+            }
+            for (; kk < c0; kk += 16) {                    // c0 is a multiple of 16: four k-steps, loads first
                 double af[4], bf[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -741,6 +754,7 @@ __device__ __forceinline__ int chol_blocked_mem(double *Lp, int n, double *panel
             cholm_load<1>(a1, ncol, lane, [&](int i, int j) { return panel[i * 17 + j]; });
             int f0 = cholm_factor<1>(a1, L11, ncol, cb, lane);
             if (lane == 0) *flag = f0;
+            if (lane < ncol) L11[136 + lane] = 1.0 / L11[pk(ncol, lane, lane)];     // reciprocal pivots for the row solves
         }
         __syncthreads();
         if (*flag >= 0) { fail = c0 + *flag; break; }
@@ -757,7 +771,7 @@ __device__ __forceinline__ int chol_blocked_mem(double *Lp, int n, double *panel
                         double sum = panel[r * 17 + b];
 #pragma unroll
                         for (int q = 0; q < b; ++q) sum -= x[q] * L11[pk(ncol, b, q)];
-                        x[b] = sum / L11[pk(ncol, b, b)];
+                        x[b] = sum * L11[136 + b];
                         Lp[pk(n, row, c0 + b)] = x[b];
                     }
                 }
@@ -2634,7 +2648,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void msckf_chol_big_kernel(KArgs a)
                                                 [&](int i, int j) { return gP[i + (size_t)j * N]; });
     if (tid == 0) a.wsfail[bidx] = fail;
 }
-__host__ inline size_t chol_big_lds(int N) { return (size_t)(16 * ((N + 15) / 16) * 17 + 4 * 34 + 136 + 8) * sizeof(double); }
+__host__ inline size_t chol_big_lds(int N) { return (size_t)(16 * ((N + 15) / 16) * 17 + 4 * 34 + 136 + 16 + 8) * sizeof(double); }
 
 // ------------------------------------------------------------------ the Msckf predict kernel
 // Msckf::predict (Msckf.hpp:89-189; state <-> clone cross-covariances stay stale, :171-182): sigma points of the current
