@@ -2219,6 +2219,47 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                     }
                 }
             };
+            // the same in two halves for the fp64 panel loop: the loads of the NEXT panel are issued before the MFMA block of
+            // the current one (the factor / the deviations may live in the global workspace) and stored to LDS after it
+            constexpr int KPW = (KP + NW - 1) / NW;                               // panel columns per wave
+            auto gen_load = [&](int p0, double (&lv)[KPW][RPT]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < KPW; ++u) {
+                    const int kk = wave + u * NW, i = p0 + kk, j = (i - 1) >> 1;
+                    const int jb = pkcol(N, j);
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q) {
+                        const int t = lane + 64 * q;
+                        const bool vec = rkind[q] == 1 && i > 0 && i < S && j <= t && kk < KP;
+                        const bool rot = rkind[q] == 2 && i < S && kk < KP;
+                        const double *src = rot ? DR + (roffs[q] + 3 * (i < rcnt[q] ? i : 0)) : Lp + (vec ? jb + t : 0);
+                        lv[u][q] = *src;
+                    }
+                }
+            };
+            auto gen_store = [&](int p0, const double (&lv)[KPW][RPT], double *Dq) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < KPW; ++u) {
+                    const int kk = wave + u * NW, i = p0 + kk, j = (i - 1) >> 1;
+                    const double sgn = (i & 1) ? 1.0 : -1.0;
+                    if (kk < KP) {
+#pragma unroll
+                        for (int q = 0; q < RPT; ++q) {
+                            const int t = lane + 64 * q;
+                            double v = 0.0;
+                            if (i < S) {
+                                if (rkind[q] == 1) {
+                                    const double l = (i > 0 && j <= t) ? sgn * lv[u][q] : 0.0;
+                                    v = (rm[q] + (rd[q] + l)) - rr[q];
+                                } else if (rkind[q] == 2) {
+                                    v = lv[u][q];
+                                }
+                            }
+                            if (rkind[q] != 3) Dq[kk * LDD + t] = v;
+                        }
+                    }
+                }
+            };
             bool rebuilt = false;
             if constexpr (NW == 4 && NT >= 3 && NT <= 4) {
                 if (a.rebuild_prec == 0) {
@@ -2527,6 +2568,9 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 int pb = 0;
                 for (int p0 = 0; p0 < S; p0 += KP, pb ^= 1) {
                     const double *Dc = Dp + pb * KP * LDD;
+                    double lnext[KPW][RPT];
+                    const bool more = p0 + KP < S;
+                    if (more) gen_load(p0 + KP, lnext);
 #pragma unroll
                     for (int ks = 0; ks < KP / 4; ++ks) {
                         double frag[NT];
@@ -2534,7 +2578,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                         for (int I = 0; I < NT; ++I) frag[I] = Dc[(4 * ks + (lane >> 4)) * LDD + 16 * I + (lane & 15)];
                         MfmaTiles<NT, NW, 0>::run(frag, acc, wave, pass);
                     }
-                    if (p0 + KP < S) gen_panel(p0 + KP, Dp + (pb ^ 1) * KP * LDD);
+                    if (more) gen_store(p0 + KP, lnext, Dp + (pb ^ 1) * KP * LDD);
                     __syncthreads();
                 }
                 SLK_STAMP(14);
