@@ -1593,7 +1593,8 @@ struct MfmaTiles {
     }
     // accumulators -> global P (column-major, both triangles).  The tile is written transposed
     // (P is symmetric), so that the 16 lanes of a row group store 128 contiguous bytes.
-    __device__ __forceinline__ static void store(double *gP, int N, const d4 (&acc)[TPW], int wave, int lane, int pass)
+    __device__ __forceinline__ static void store(double *gP, int N, const d4 (&acc)[TPW], int wave, int lane, int pass,
+                                                 double scale = 0.5)
     {
         if constexpr (T < TileMap<NT>::NTILES) {
             if ((T % NW) == wave && (T / PER_PASS) == pass) {
@@ -1603,13 +1604,57 @@ struct MfmaTiles {
                 for (int r = 0; r < 4; ++r) {
                     int rr = 16 * I + (lane >> 4) + 4 * r;
                     if (rr < N && c < N) {
-                        double v = 0.5 * acc[(T % PER_PASS) / NW][r];
+                        double v = scale * acc[(T % PER_PASS) / NW][r];
                         gP[c + (size_t)rr * N] = v;
                         if (I != J) gP[rr + (size_t)c * N] = v;
                     }
                 }
             }
-            MfmaTiles<NT, NW, T + 1>::store(gP, N, acc, wave, lane, pass);
+            MfmaTiles<NT, NW, T + 1>::store(gP, N, acc, wave, lane, pass, scale);
+        }
+    }
+    // accumulator tiles -> LDS, tile T at T * 272, element (row, col) at col * 17 + row
+    __device__ __forceinline__ static void to_lds(double *dst, const d4 (&acc)[TPW], int wave, int lane)
+    {
+        if constexpr (T < TileMap<NT>::NTILES) {
+            if ((T % NW) == wave) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[T * 272 + (lane & 15) * 17 + (lane >> 4) + 4 * r] = acc[T / NW][r];
+            }
+            MfmaTiles<NT, NW, T + 1>::to_lds(dst, acc, wave, lane);
+        }
+    }
+    // rotation-row index of a tangent row of the Msckf layout (-1: a vector row): State.hpp:141-149, :246-252, :384-396
+    __device__ __forceinline__ static int rho_of(int t)
+    {
+        if (t < 12) return (t >= 3 && t < 6) ? t - 3 : -1;
+        const int cc = (t - 12) / 6, r = (t - 12) - 6 * cc;
+        return r >= 3 ? 3 * cc + r : -1;
+    }
+    // store (scale 1) plus the matrix EEt given in the index space of the rotation rows (lower tiles as written by to_lds)
+    __device__ __forceinline__ static void store_plus_rot(double *gP, int N, const d4 (&acc)[TPW], int wave, int lane, const double *EEt)
+    {
+        if constexpr (T < TileMap<NT>::NTILES) {
+            if ((T % NW) == wave) {
+                constexpr int I = TileMap<NT>::row(T), J = TileMap<NT>::col(T);
+                const int c = 16 * J + (lane & 15), rc = rho_of(c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = 16 * I + (lane >> 4) + 4 * r;
+                    if (rr < N && c < N) {
+                        const int r1 = rho_of(rr);
+                        double v = acc[T / NW][r];
+                        if (r1 >= 0 && rc >= 0) {
+                            const int hi = r1 > rc ? r1 : rc, lo = r1 > rc ? rc : r1;
+                            const int ti = hi >> 4, tj = lo >> 4;
+                            v += EEt[(ti * (ti + 1) / 2 + tj) * 272 + (lo & 15) * 17 + (hi & 15)];
+                        }
+                        gP[c + (size_t)rr * N] = v;
+                        if (I != J) gP[rr + (size_t)c * N] = v;
+                    }
+                }
+            }
+            MfmaTiles<NT, NW, T + 1>::store_plus_rot(gP, N, acc, wave, lane, EEt);
         }
     }
 };
@@ -2150,20 +2195,37 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 }
             }
             if (!oe_rebuild && it < 10000) {
-                // the same correction for the shapes without the odd / even rebuild, in place (formula: see below)
-                for (int w = tid; w < W; w += NTHREADS) {
-                    const int to = ((unsigned)a.rtab[w] >> 20) & 0xff;
-                    const double m0 = md[to], m1 = md[to + 1], m2 = md[to + 2];
-                    const double x = DR[3 * w], y = DR[3 * w + 1], z = DR[3 * w + 2];
+                // the same correction for the shapes without the N <= 64 odd / even rebuild, in place (formula: see below);
+                // large states: their odd / even rebuild wants each pair as (d+ - d-) / 2, (d+ + d-) / 2 -- same pass
+                const bool pairs = BIG && a.rebuild_prec == 0;
+                auto fix = [&](double &x, double &y, double &z, double m0, double m1, double m2) {
                     const double cx = y * m2 - z * m1, cy = z * m0 - x * m2, cz = x * m1 - y * m0;      // d x m
                     const double ax = y * cz - z * cy, ay = z * cx - x * cz, az = x * cy - y * cx;      // d x (d x m)
                     const double a12 = 1.0 / 12.0 + (x * x + y * y + z * z) * (1.0 / 720.0);
-                    DR[3 * w] = x - m0 + 0.5 * cx - a12 * ax;
-                    DR[3 * w + 1] = y - m1 + 0.5 * cy - a12 * ay;
-                    DR[3 * w + 2] = z - m2 + 0.5 * cz - a12 * az;
+                    x = x - m0 + 0.5 * cx - a12 * ax;
+                    y = y - m1 + 0.5 * cy - a12 * ay;
+                    z = z - m2 + 0.5 * cz - a12 * az;
+                };
+                for (int w = tid; w < W; w += NTHREADS) {
+                    const unsigned lo = (unsigned)a.rtab[w];
+                    const unsigned sc = (lo >> 18) & 3u;
+                    if (pairs && sc == 2u) continue;                             // a '-' item: done by its '+' partner
+                    const int to = (lo >> 20) & 0xff;
+                    const double m0 = md[to], m1 = md[to + 1], m2 = md[to + 2];
+                    double px = DR[3 * w], py = DR[3 * w + 1], pz = DR[3 * w + 2];
+                    fix(px, py, pz, m0, m1, m2);
+                    if (pairs && sc == 1u) {
+                        double qx = DR[3 * w + 3], qy = DR[3 * w + 4], qz = DR[3 * w + 5];
+                        fix(qx, qy, qz, m0, m1, m2);
+                        DR[3 * w] = 0.5 * (px - qx); DR[3 * w + 1] = 0.5 * (py - qy); DR[3 * w + 2] = 0.5 * (pz - qz);
+                        DR[3 * w + 3] = 0.5 * (px + qx); DR[3 * w + 4] = 0.5 * (py + qy); DR[3 * w + 5] = 0.5 * (pz + qz);
+                    } else {
+                        DR[3 * w] = px; DR[3 * w + 1] = py; DR[3 * w + 2] = pz;
+                    }
                 }
                 __syncthreads();
             }
+            const bool big_oe = BIG && a.rebuild_prec == 0 && it < 10000;
             if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
             SLK_STAMP(12);
             SLK_NOTE(20, it + 1);
@@ -2554,6 +2616,102 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                         }
                         __syncthreads();
                     }
+                    rebuilt = true;
+                }
+            }
+            if constexpr (BIG && TilePlan<NT, NW>::PASSES == 1) {
+                if (big_oe) {
+                    // ---- Odd / even rebuild for the large states, through the LDS panels: P+ = O O^T + E E^T + 1/2 d_0 d_0^T
+                    // (see the N <= 64 version above).  A panel column is now a COLUMN j of the pair structure: O(:, j) =
+                    // L'(:, j) for the vector rows (read as it lies in the factor) and the odd parts of the stored pairs
+                    // for the rotation rows -- N + 1 columns instead of the 2 N + 1 sigma points; E lives in the index
+                    // space of the rotation rows (rho = 3 b + comp), its column j the even parts (d_0 beyond the block's
+                    // own columns), column N = d_0 / sqrt(2); its tiles are added to the covariance where they belong.
+                    constexpr int NTE = (3 * (1 + (16 * NT - 12) / 6) + 15) / 16;         // tile rows of E
+                    constexpr int LDE = 16 * NTE;
+                    constexpr int TPWE = TilePlan<NTE, NW>::TPW;
+                    static_assert(TilePlan<NTE, NW>::PASSES == 1, "E tiles in one pass");
+                    double *Ep = Dp + 2 * KP * LDD;                                    // [2][KP][LDE]
+                    const int nrot = 3 * nso3, NC = N + 1;
+                    auto gen_oe_load = [&](int j0, double (&lv)[KPW][RPT], double (&ev)[KPW][2]) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int u = 0; u < KPW; ++u) {
+                            const int kk = wave + u * NW, j = j0 + kk;
+                            const int jb = pkcol(N, j < N ? j : 0);
+#pragma unroll
+                            for (int q = 0; q < RPT; ++q) {
+                                const int t = lane + 64 * q;
+                                const bool vec = rkind[q] == 1 && j < N && j <= t && kk < KP;
+                                const bool rot = rkind[q] == 2 && j < N && 1 + 2 * j < rcnt[q] && kk < KP;
+                                const double *src = rot ? DR + (roffs[q] + 3 * (1 + 2 * j)) : Lp + (vec ? jb + t : 0);
+                                const double v = *src;
+                                lv[u][q] = (vec || rot) ? v : 0.0;
+                            }
+#pragma unroll
+                            for (int qe = 0; qe < 2; ++qe) {
+                                const int rho = lane + 64 * qe;
+                                const bool in = rho < nrot && j < NC && kk < KP;
+                                const int b = in ? rho / 3 : 0, comp = rho - 3 * b;
+                                const int cnt = msckf_roff(b + 1) - msckf_roff(b), base = 3 * msckf_roff(b) + comp;
+                                const bool pair = j < N && 2 + 2 * j < cnt;
+                                const double v = DR[in ? base + (pair ? 3 * (2 + 2 * j) : 0) : 0];
+                                ev[u][qe] = in ? (j == N ? v * 0.70710678118654752440 : v) : 0.0;
+                            }
+                        }
+                    };
+                    auto gen_oe_store = [&](const double (&lv)[KPW][RPT], const double (&ev)[KPW][2], double *Dq, double *Eq)
+                        __attribute__((always_inline)) {
+#pragma unroll
+                        for (int u = 0; u < KPW; ++u) {
+                            const int kk = wave + u * NW;
+                            if (kk < KP) {
+#pragma unroll
+                                for (int q = 0; q < RPT; ++q) {
+                                    const int t = lane + 64 * q;
+                                    if (rkind[q] != 3) Dq[kk * LDD + t] = lv[u][q];
+                                }
+#pragma unroll
+                                for (int qe = 0; qe < 2; ++qe) {
+                                    const int rho = lane + 64 * qe;
+                                    if (rho < LDE) Eq[kk * LDE + rho] = ev[u][qe];
+                                }
+                            }
+                        }
+                    };
+                    d4 acc[TPW], accE[TPWE];
+#pragma unroll
+                    for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < TPWE; ++q) accE[q] = d4{0.0, 0.0, 0.0, 0.0};
+                    double lvn[KPW][RPT], evn[KPW][2];
+                    gen_oe_load(0, lvn, evn);
+                    gen_oe_store(lvn, evn, Dp, Ep);
+                    __syncthreads();
+                    int pb = 0;
+                    for (int j0 = 0; j0 < NC; j0 += KP, pb ^= 1) {
+                        const double *Dc = Dp + pb * KP * LDD, *Ec = Ep + pb * KP * LDE;
+                        const bool more = j0 + KP < NC;
+                        if (more) gen_oe_load(j0 + KP, lvn, evn);            // the next panel's operands: in flight under the MFMAs
+#pragma unroll
+                        for (int ks = 0; ks < KP / 4; ++ks) {
+                            double frag[NT], fragE[NTE];
+#pragma unroll
+                            for (int I = 0; I < NT; ++I) frag[I] = Dc[(4 * ks + (lane >> 4)) * LDD + 16 * I + (lane & 15)];
+#pragma unroll
+                            for (int I = 0; I < NTE; ++I) fragE[I] = Ec[(4 * ks + (lane >> 4)) * LDE + 16 * I + (lane & 15)];
+                            MfmaTiles<NT, NW, 0>::run(frag, acc, wave, 0);
+                            MfmaTiles<NTE, NW, 0>::run(fragE, accE, wave, 0);
+                        }
+                        if (more) gen_oe_store(lvn, evn, Dp + (pb ^ 1) * KP * LDD, Ep + (pb ^ 1) * KP * LDE);
+                        __syncthreads();
+                    }
+                    SLK_STAMP(14);
+                    // E E^T (+ 1/2 d_0 d_0^T) meets the O O^T tiles in LDS: the panels are dead, the E tiles go to the pool
+                    // (lower triangle of tiles, 16 x 17 each) and every stored element picks up its own
+                    double *EEt = pool;
+                    MfmaTiles<NTE, NW, 0>::to_lds(EEt, accE, wave, lane);
+                    __syncthreads();
+                    MfmaTiles<NT, NW, 0>::store_plus_rot(oP, N, acc, wave, lane, EEt);
                     rebuilt = true;
                 }
             }
