@@ -214,7 +214,7 @@ template <int NT, int NTHREADS, int KST = -1, int MST = 0>
 static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
 {
     KArgs a = a0;
-    constexpr bool BIG = NT > 5;
+    constexpr bool BIG = NT > 4;
     Carve cv = carve_step(a.lay, a.m, NT, BIG, a.rebuild_prec);
     if (f->rtab_k != a.lay.k) {                 // layout changed (first launch, slk_msckf_resize): new descriptor table
         std::vector<unsigned long long> tab((size_t)cv.W);

@@ -142,7 +142,7 @@ struct Carve {
     int S, LDD, TN, W;   // W = rotation-row items that differ from X_0 (sum over blocks of rot_count)
 };
 
-// big = large-state variant (NT > 5, i.e. N > 80): the packed factor and the rotation deviations live in a global
+// big = large-state variant (NT > 4, i.e. N > 64): the packed factor and the rotation deviations live in a global
 // workspace, LDS keeps the small vectors, the measurement arrays, a Cholesky panel and the MFMA panels
 // doubles reserved for Z [S][m]; where the factor-update path can run (one tile row per wave, m <= 8) its W buffer
 // (BW_SIZE = 512 doubles) takes Z's place after the moments, so the region is at least that large
@@ -1711,9 +1711,9 @@ struct MfmaTiles32 {
 // packed-index arithmetic fold); KST < 0: taken from the arguments.
 // MST > 0: the number of measurement rows is a compile-time constant too (every LDS offset of the carve folds).
 template <int NT, int NTHREADS, int KST = -1, int MST = 0>
-__global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? SLK_WGS : (NT == 5 ? 3 : ((NT >= 6 && NT <= 8) ? 2 : (NT <= 2 ? 4 : 1))))) void msckf_step_kernel(KArgs a)
+__global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? SLK_WGS : ((NT >= 5 && NT <= 8) ? 2 : (NT <= 2 ? 4 : 1)))) void msckf_step_kernel(KArgs a)
 {
-    constexpr bool BIG = NT > 5;                           // large state: factor + rotation store in the global workspace
+    constexpr bool BIG = NT > 4;                           // large state (N > 64): factor + rotation store in the global workspace
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NTHREADS / 64;
     constexpr int GD = Grid<NTHREADS>::GD;
