@@ -324,8 +324,16 @@ static int launch_msckf(slk_filter *f, const KArgs &a0)
     g_err = "development build: N = 49..64 only"; return SLK_E_UNSUPPORTED;
 #else
     switch (NT) {
-    case 1: return launch_msckf_inst<1, 64>(f, a);
-    case 2: return launch_msckf_inst<2, 64>(f, a);
+    case 1: {                                   // N = 12 (BASELINE config 2): exact shape, with m = 3 rows exact offsets too
+        const bool mx = a.do_update && a.emit == 0 && a.rebuild_prec == 0;
+        if (a.lay.k == 0 && a.m == 3 && mx) return launch_msckf_inst<1, 64, 0, 3>(f, a);
+        return (a.lay.k == 0) ? launch_msckf_inst<1, 64, 0>(f, a) : launch_msckf_inst<1, 64>(f, a);
+    }
+    case 2: {                                   // N = 18
+        const bool mx = a.do_update && a.emit == 0 && a.rebuild_prec == 0;
+        if (a.lay.k == 1 && a.m == 2 && mx) return launch_msckf_inst<2, 64, 1, 2>(f, a);
+        return (a.lay.k == 1) ? launch_msckf_inst<2, 64, 1>(f, a) : launch_msckf_inst<2, 64>(f, a);
+    }
     case 3: return launch_msckf_n48(f, a);
     case 4: return launch_msckf_n60(f, a);
     case 5: return launch_msckf_inst<5, 256>(f, a);
