@@ -138,7 +138,7 @@ __device__ __forceinline__ double Lz(const double *Lp, int n, int t, int j)
 
 // ------------------------------------------------------------------ LDS carve (in doubles)
 struct Carve {
-    int Lp, mu, ref, delta, md, cq, small, colbuf, pool, total;
+    int Lp, mu, ref, delta, md, cq, pn12, small, colbuf, pool, total;
     int S, LDD, TN, W;   // W = rotation-row items that differ from X_0 (sum over blocks of rot_count)
 };
 
@@ -172,6 +172,7 @@ __host__ __device__ inline Carve carve_step(const Lay &L, int m, int NT, bool bi
     c.delta = o;  o += round_up(N, 2);
     c.md = o;     o += round_up(N, 2);
     c.cq = o;     o += 4 * L.nso3;                 // ref_b^-1 * mu_b per SO(3) block (mean loop)
+    c.pn12 = o;   o += (NT <= 2) ? 144 : 0;        // the predicted 12 x 12 block (one-wave kernels: predict runs inside)
     c.small = o;  o += 96;
     c.colbuf = o; o += big ? (4 * 34 + 136 + 16) : 4 * ((c.TN > 32 ? c.TN : 32) + 2);   // big: cholm<1..2> buffer + packed 16x16 factor + its reciprocal pivots
     c.pool = o;
@@ -1754,8 +1755,30 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
     // state's 12 x 12 block only, keeps one wave busy per filter and nothing of it is reused on chip -- beside the
     // four-wave phases of this kernel it held three waves and 38 KB of LDS idle for 13 % of the step.
     constexpr bool WCHOL = NT >= 3 && NT <= 4 && NW >= NT;       // one tile row per wave
+    // N <= 32: the workgroup IS one wave, the predict chain runs here (one launch per step: the step time of these shapes
+    // is one filter's latency); the update reads the predicted block from LDS
+    bool pred12 = false;
+    const double *Pn12 = smem + cv.pn12;
+    if constexpr (NT <= 2) {
+        if (a.do_predict) {
+            double *Lblk = pool, *Pn = pool + 160, *scr = pool + 320;          // 320 + 736 <= PRED_SCRATCH
+            const int st = predict_phase<false>(a, bidx, tid, [&](int i, int j) { return gP[i + (size_t)j * N]; }, Lblk, mu, Pn, scr,
+                                                nullptr);
+            if (st < 0) return;                              // sigma points emitted
+            status |= st;
+            if (!(st & SLK_ST_LLT_FAIL)) {                   // else: predict skipped, filter unchanged
+                for (int e = tid; e < 144; e += NTHREADS) {
+                    smem[cv.pn12 + e] = Pn[e];
+                    gP[(e % 12) + (size_t)(e / 12) * N] = Pn[e];
+                }
+                if (tid < 13) gmean[tid] = mu[tid];
+                pred12 = true;
+            }
+            __syncthreads();
+        }
+    }
     // lower-triangle element of the covariance (only the lower triangle of Pk is ever read: LLT at :412, :447)
-    auto Pin = [&](int i, int j) -> double { return gP[i + (size_t)j * N]; };
+    auto Pin = [&](int i, int j) -> double { return (NT <= 2 && pred12 && i < 12 && j < 12) ? Pn12[i + 12 * j] : gP[i + (size_t)j * N]; };
 
     SLK_STAMP(2);
     if (a.do_update || a.emit >= 2) {
