@@ -389,6 +389,9 @@ static int launch_usckf_split(slk_filter *f, const KArgs &a0)
 #define SLK_USCKF_UPD_THREADS 128   // two waves per filter: twice the filters in flight, fewer barrier waits (A/B: 256 -> 188 us, 128 -> 165 us, 64 -> 172 us at B = 4096)
 #endif
     auto kern = usckf_kernel<NT, SLK_USCKF_UPD_THREADS, true>;
+    if constexpr (NT == 3) {                    // the unit-test shape: exact instantiation
+        if (a.lay.nfk == 3 && a.lay.nfkl == 9 && a.m == 3) kern = usckf_kernel<3, SLK_USCKF_UPD_THREADS, true, true>;
+    }
     rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), f->cfg.device, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(SLK_USCKF_UPD_THREADS), lds, f->stream, a);

@@ -31,7 +31,9 @@ __host__ __device__ inline UCarve carve_usckf(int N, int Nq, int m, int NT, bool
 // SPLIT (N <= 64, three launches per step like the Msckf path): predict runs in usckf_predict_kernel, the factorisation in
 // msckf_chol_kernel (one wave per filter each), and this kernel is the update alone: the covariance stays in global
 // memory (its diagonal for the moments, the downdate as a read-modify-write), the factor comes from the workspace.
-template <int NT, int NTHREADS, bool SPLIT = false>
+// UEX: exact-shape instantiation of the unit-test layout (UsckfUnitTest.cpp: 3 + 9 features, N = 48, m = 3 rows): layout
+// and packed-index arithmetic fold.
+template <int NT, int NTHREADS, bool SPLIT = false, bool UEX = false>
 __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -40,7 +42,8 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
     constexpr int SDN = (16 * NT + GD - 1) / GD;
     constexpr int SDM = (MAXM + GD - 1) / GD;
     const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const Lay L = a.lay;
+    Lay L = a.lay;
+    if constexpr (UEX) { L.kind = SLK_USCKF; L.nfk = 3; L.nfkl = 9; L.N = 48; L.Nq = 51; L.nso3 = 3; a.m = 3; }
     const int N = L.N, Nq = L.Nq, m = a.m;
     const UCarve cv = carve_usckf(N, Nq, m, NT, SPLIT);
     const int lda = cv.lda, S = cv.S;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
 // 12-DOF prediction of state k+i (predict_phase), Fk = Pxy^T Pk_i^-1 (:154), then the cross blocks: rows of state k+i
 // against everything else Fk * block (:200-208, :221-232), columns against statek / statek_l block * Fk^T (:190-198),
 // feature rows as transposes (:227, :235).  All old values are staged in LDS before the first write.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void usckf_predict_kernel(KArgs a)
+__global__ __launch_bounds__(64, 2) void usckf_predict_kernel(KArgs a)
 {
     __shared__ __attribute__((aligned(16))) double sm[16 + 4 * 160 + 736 + 288];
     const int bidx = blockIdx.x, tid = threadIdx.x;
