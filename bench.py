@@ -74,7 +74,7 @@ def cpu_baseline(k, m, seed, threads=1):
     import scenarios as sc
     N = 12 + 6 * k
     per_thread = max(8, int(64 * (60.0 / N) ** 3))          # ~10 s of CPU work per thread at any N
-    Bc, steps = per_thread * threads, 250 if threads == 1 else 150
+    Bc, steps = per_thread * threads, 1200 if threads == 1 else 900      # ~10 s of CPU work on this host per leg
     s = sc.synthetic_msckf(Bc, k, m=m, seed=seed)
     mean, P = s["mean"].copy(), s["P"].copy()
     o.lib()
