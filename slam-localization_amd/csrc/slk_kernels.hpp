@@ -2191,7 +2191,24 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                     const int blk = e / 3, comp = e - 3 * blk, sub = tid & 7;
                     const int r0 = msckf_roff(blk), cnt = msckf_roff(blk + 1) - r0;
                     const double *row = DR + 3 * r0 + comp;
-                    double sum = group_sum<8>(sub, cnt, [&](int i) { return row[3 * i]; });
+                    double sum;
+                    if constexpr (BIG) {
+                        // the deviation store is in global memory: sixteen loads in flight per lane, four accumulators
+                        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+                        for (int i0 = sub; i0 < cnt; i0 += 8 * 16) {
+                            double v[16];
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) { const int i = i0 + 8 * u; v[u] = (i < cnt) ? row[3 * i] : 0.0; }
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) s4[u & 3] += v[u];
+                        }
+                        sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+                        sum += __shfl_xor(sum, 4, 64);
+                        sum += __shfl_xor(sum, 2, 64);
+                        sum += __shfl_xor(sum, 1, 64);
+                    } else {
+                        sum = group_sum<8>(sub, cnt, [&](int i) { return row[3 * i]; });
+                    }
                     sum += (double)(S - cnt) * row[0];
                     if (sub == 0) md[msckf_toff(blk) + comp] = sum / (double)S;
                 }
