@@ -79,7 +79,9 @@ def test_msckf_batch_golden_with_outliers(slk):
                                    # one tile row per wave (N = 36 .. 60) with fewer than 8 rows: the factor-update path
                                    (4, 2, 16), (5, 4, 16), (6, 6, 16), (7, 2, 8), (8, 4, 16), (8, 6, 16),
                                    # exact-shape instantiations (m = 8): k = 4 .. 7
-                                   (4, 8, 16), (5, 8, 16), (6, 8, 16), (7, 8, 16)])
+                                   (4, 8, 16), (5, 8, 16), (6, 8, 16), (7, 8, 16),
+                                   # large-state factor update / odd-even rebuild with fewer than 8 rows
+                                   (9, 2, 4), (12, 4, 4), (16, 6, 4), (20, 2, 3), (31, 4, 2), (32, 6, 2)])
 def test_msckf_step_against_oracle(slk, k, m, B):
     s = sc.synthetic_msckf(B, k, m=m, seed=100 + k)
     lay = o.layout(o.MULTI, k)
