@@ -102,6 +102,33 @@ def test_msckf_step_against_oracle(slk, k, m, B):
         assert mean_err(lay, Mg[b], mean[b]) <= TOL, b
 
 
+@pytest.mark.parametrize("k,B", [(8, 12), (12, 6), (19, 4), (31, 3)])
+def test_msckf_rejected_rows_in_the_factor_update(slk, k, B):
+    # a feature pushed out of the gate: its two rows drop out of the factor update (identity row / column of the prefix
+    # matrices) -- the N = 60 kernel and the large-state path against the oracle, outlier counts included
+    m = 8
+    s = sc.synthetic_msckf(B, k, m=m, seed=900 + k)
+    z = s["z"].copy()
+    z[::2, 2:4] += 0.8                       # every other filter: feature 1 far off
+    z[1::3, 6:8] -= 0.9                      # every third: feature 3 too
+    lay = o.layout(o.MULTI, k)
+    N = s["N"]
+    f = slk.Msckf(s["mean"], s["P"])
+    tot = np.zeros(B, dtype=np.int64)
+    for _ in range(2):
+        f.step(slk.PM_DELTA_POSE, s["u"], s["Q"], z, slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+        tot += f.outliers()
+    mean, P = s["mean"].copy(), s["P"].copy()
+    st, out = o.msckf_step_batch(k, m, 2, mean, P, s["u"], s["feat"], z, s["Q"], s["R"])
+    assert st == 0 and (f.status() & ~slk.ST_ALL_REJECTED == 0).all()
+    np.testing.assert_array_equal(tot, out)
+    assert tot.sum() > 0
+    Pg, Mg = f.getPk(), f.muState()
+    for b in range(B):
+        assert rel(Pg[b], P[b].reshape(N, N).T) <= TOL, b
+        assert mean_err(lay, Mg[b], mean[b]) <= TOL, b
+
+
 def test_separate_predict_update_equals_fused_step(slk):
     s = sc.synthetic_msckf(16, 4, m=8, seed=7)
     a = slk.Msckf(s["mean"], s["P"])
