@@ -129,6 +129,27 @@ def test_msckf_rejected_rows_in_the_factor_update(slk, k, B):
         assert mean_err(lay, Mg[b], mean[b]) <= TOL, b
 
 
+@pytest.mark.parametrize("k,m,B", [(2, 4, 4), (8, 8, 4), (12, 8, 3), (31, 8, 2)])
+def test_msckf_update_with_a_wrapped_rotation_column(slk, k, m, B):
+    # a rotation variance beyond pi^2: a column of the factor is longer than pi, log(exp(v)) wraps (MTK's atan form) and
+    # covXZ is no longer L A -- the kernels leave the factor-update path for the plain one (large states: the blocked
+    # factorisation of the downdated matrix)
+    s = sc.synthetic_msckf(B, k, m=m, seed=1200 + k)
+    N = s["N"]
+    P = s["P"].copy().reshape(B, N, N)
+    P[:, 4, 4] += 11.0
+    P = np.ascontiguousarray(P)
+    lay = o.layout(o.MULTI, k)
+    f = slk.Msckf(s["mean"], P)
+    f.update(s["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"], gate=0)
+    Pg, Mg = f.getPk(), f.muState()
+    for b in range(B):
+        r = o.Msckf(k, s["mean"][b], P[b])
+        st, _ = r.update(s["z"][b], o.mm_feature_proj(s["feat"][b]), s["R"], gate=False)
+        assert st == 0 and f.status()[b] == 0
+        assert rel(Pg[b], r.P) <= TOL and mean_err(lay, Mg[b], r.mean) <= TOL
+
+
 def test_separate_predict_update_equals_fused_step(slk):
     s = sc.synthetic_msckf(16, 4, m=8, seed=7)
     a = slk.Msckf(s["mean"], s["P"])
