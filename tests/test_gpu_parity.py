@@ -150,6 +150,24 @@ def test_msckf_update_with_a_wrapped_rotation_column(slk, k, m, B):
         assert rel(Pg[b], r.P) <= TOL and mean_err(lay, Mg[b], r.mean) <= TOL
 
 
+@pytest.mark.parametrize("k,m,B", [(2, 4, 3), (8, 8, 3), (12, 8, 3), (31, 8, 2)])
+def test_msckf_update_with_a_non_spd_innovation_covariance(slk, k, m, B):
+    # R = -0.3 I makes S = cov(Z) + R indefinite: the reference inverts it with PartialPivLU all the same (Msckf.hpp:257);
+    # the kernels leave the Cholesky-based gain and the factor update for Gauss-Jordan + a fresh factorisation
+    s = sc.synthetic_msckf(B, k, m=m, seed=1300 + k)
+    N = s["N"]
+    R = -0.3 * np.eye(m)
+    lay = o.layout(o.MULTI, k)
+    f = slk.Msckf(s["mean"], s["P"])
+    f.update(s["z"], slk.MM_FEATURE_PROJ, s["feat"], R, gate=0)
+    Pg, Mg = f.getPk(), f.muState()
+    for b in range(B):
+        r = o.Msckf(k, s["mean"][b], s["P"][b].reshape(N, N))
+        st, _ = r.update(s["z"][b], o.mm_feature_proj(s["feat"][b]), R, gate=False)
+        assert st == 0 and f.status()[b] == 0
+        assert rel(Pg[b], r.P) <= TOL and mean_err(lay, Mg[b], r.mean) <= TOL
+
+
 def test_separate_predict_update_equals_fused_step(slk):
     s = sc.synthetic_msckf(16, 4, m=8, seed=7)
     a = slk.Msckf(s["mean"], s["P"])
