@@ -5,7 +5,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "slk_api.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("slk_api.hip", "slk_kernels.hpp", "slk_usckf.hpp", "slk_math.hpp", "slk_ekf.hpp", "slk_ekf_tiles.hpp", "slk_pose.hpp")]
+# translation units of the product build (compiled in parallel, then linked): the host side + most kernels, and the
+# explicit instantiations of the largest step kernels
+UNITS = [os.path.join(HERE, "csrc", f) for f in ("slk_api.hip", "slk_inst_big.hip", "slk_inst_mid.hip")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("slk_api.hip", "slk_inst_big.hip", "slk_inst_mid.hip", "slk_kernels.hpp", "slk_usckf.hpp",
+                                                "slk_math.hpp", "slk_ekf.hpp", "slk_ekf_tiles.hpp", "slk_pose.hpp")]
 DEPS.append(os.path.join(os.path.dirname(HERE), "include", "slk.h"))
 OUT = os.path.join(HERE, "libslk_hip.so")
 
@@ -39,12 +43,19 @@ def build(force=False, verbose=False, stamps=False):
     out = OUT.replace(".so", "_stamps.so") if stamps else OUT
     if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in DEPS):
         return out
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", out, SRC]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
     if stamps:
-        cmd.insert(1, "-DSLK_STAMPS")
+        flags.append("-DSLK_STAMPS")
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+        flags.append("-Rpass-analysis=kernel-resource-usage")
+    obj_dir = os.path.join(HERE, "_build_stamps" if stamps else "_build")
+    os.makedirs(obj_dir, exist_ok=True)
+    objs = [os.path.join(obj_dir, os.path.basename(u).replace(".hip", ".o")) for u in UNITS]
+    procs = [subprocess.Popen([hipcc()] + flags + ["-c", u, "-o", o]) for u, o in zip(UNITS, objs)]
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise subprocess.CalledProcessError(max(rcs), "hipcc -c (one of %s)" % ", ".join(os.path.basename(u) for u in UNITS))
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out
 
 

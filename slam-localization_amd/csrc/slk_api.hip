@@ -20,6 +20,19 @@
 #include "slk_ekf_tiles.hpp"
 #include "slk_pose.hpp"
 
+// The largest step-kernel instantiations are compiled in translation units of their own (slk_inst_big.hip,
+// slk_inst_mid.hip) so that the library's build runs them in parallel; development builds (one file) keep none of them.
+#if !defined(SLK_DEV_N60) && !defined(SLK_ONE_TU)
+namespace slk {
+extern template __global__ void msckf_step_kernel<13, 512, -1, 0>(KArgs);
+extern template __global__ void msckf_step_kernel<13, 512, 31, 8>(KArgs);
+extern template __global__ void msckf_step_kernel<10, 512, -1, 0>(KArgs);
+extern template __global__ void msckf_step_kernel<8, 256, -1, 0>(KArgs);
+extern template __global__ void msckf_step_kernel<6, 256, -1, 0>(KArgs);
+extern template __global__ void msckf_step_kernel<5, 256, -1, 0>(KArgs);
+} // namespace slk
+#endif
+
 using namespace slk;
 
 static thread_local std::string g_err;

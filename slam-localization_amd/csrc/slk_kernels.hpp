@@ -2898,6 +2898,7 @@ __host__ inline size_t chol_big_lds(int N) { return (size_t)(16 * ((N + 15) / 16
 // LDS): the phase is a chain of small dependent steps, so its throughput comes from many filters per SIMD -- up to
 // eight resident waves here against the single busy wave per four it had inside the fused step kernel.
 // Also the Tier-B halves: emit == 1 writes the 25 sigma points, pm == SLK_MODEL_EXTERNAL takes f(X) from Yext.
+#ifndef SLK_INST_UNIT     // (non-template kernels: defined in the main translation unit only)
 #ifndef SLK_PRED_WAVES
 #define SLK_PRED_WAVES 4     // waves per SIMD the predict kernel is compiled for
 #endif
@@ -2920,7 +2921,10 @@ __global__ __launch_bounds__(64, SLK_PRED_WAVES) void msckf_predict_kernel(KArgs
     if (tid == 0 && st) atomicOr(a.status + bidx, st);
 }
 
+#endif
+
 // ------------------------------------------------------------------ MFMA fragment layout self test
+#ifndef SLK_INST_UNIT
 __global__ void selftest_mfma_kernel(const double *Amat /*16x4 row-major*/, const double *Bmat /*4x16 row-major*/,
                                      double *C /*16x16 row-major*/)
 {
@@ -2929,5 +2933,7 @@ __global__ void selftest_mfma_kernel(const double *Amat /*16x4 row-major*/, cons
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Amat[(l & 15) * 4 + (l >> 4)], Bmat[(l >> 4) * 16 + (l & 15)], acc, 0, 0, 0);
     for (int r = 0; r < 4; ++r) C[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
 }
+
+#endif
 
 } // namespace slk
