@@ -137,7 +137,13 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
         int fail;
         if constexpr (SPLIT) {
             const double *gL = a.wsL + (size_t)bidx * pk_size(N);
-            for (int e = tid; e < pk_size(N); e += NTHREADS) Lm[e] = gL[e];
+            for (int e0 = 0; e0 < pk_size(N); e0 += 12 * NTHREADS) {      // twelve loads in flight per thread
+                double v[12];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) { const int e = e0 + q * NTHREADS + tid; v[q] = (e < pk_size(N)) ? gL[e] : 0.0; }
+#pragma unroll
+                for (int q = 0; q < 12; ++q) { const int e = e0 + q * NTHREADS + tid; if (e < pk_size(N)) Lm[e] = v[q]; }
+            }
             fail = a.wsfail[bidx];
             __syncthreads();
         } else if constexpr (NT <= 4) {
@@ -254,16 +260,17 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
                     }
                     // Pk -= K S K^T (:296); K S = covXZ
                     if constexpr (SPLIT) {
-                        // read-modify-write of the covariance in global memory: eight elements per thread in flight
-                        for (int e0 = 0; e0 < N * N; e0 += 8 * NTHREADS) {
-                            double pv[8];
+                        // read-modify-write of the covariance in global memory: its loads first, all in flight
+                        constexpr int DQ = (NTHREADS >= 256) ? 8 : 18;          // 48 x 48 at two waves: one batch
+                        for (int e0 = 0; e0 < N * N; e0 += DQ * NTHREADS) {
+                            double pv[DQ];
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) {
+                            for (int q = 0; q < DQ; ++q) {
                                 const int e = e0 + q * NTHREADS + tid;
                                 pv[q] = (e < N * N) ? P[e] : 0.0;
                             }
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) {
+                            for (int q = 0; q < DQ; ++q) {
                                 const int e = e0 + q * NTHREADS + tid;
                                 if (e < N * N) {
                                     const int i = e % N, j = e / N;
