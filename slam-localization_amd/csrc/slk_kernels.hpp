@@ -1788,7 +1788,13 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
             // the factor comes from msckf_chol_kernel (its own launch, one wave per filter at twelve filters per CU),
             // packed, through a workspace
             const double *gL = a.wsL + (size_t)bidx * pk_size(N);
-            for (int e = tid; e < pk_size(N); e += NTHREADS) Lp[e] = gL[e];
+            for (int e0 = 0; e0 < pk_size(N); e0 += 8 * NTHREADS) {         // eight loads in flight per thread
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int e = e0 + q * NTHREADS + tid; v[q] = (e < pk_size(N)) ? gL[e] : 0.0; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int e = e0 + q * NTHREADS + tid; if (e < pk_size(N)) Lp[e] = v[q]; }
+            }
             fail = a.wsfail[bidx];
             __syncthreads();
         } else if constexpr (NT <= 4) {
