@@ -355,8 +355,17 @@ __global__ __launch_bounds__(64, 2) void usckf_predict_kernel(KArgs a)
             for (int r = 0; r < 12; ++r) Fk[tid + 12 * r] = x[r];      // column tid of Fk^T = row tid of Fk
         }
         double *RB = scr;                            // old rows 24..35 of P: 12 x N (ld 12); the predict scratch is dead
-        for (int e = tid; e < 12 * N; e += 64) RB[e] = gP[(24 + e % 12) + (size_t)(e / 12) * N];
-        for (int e = tid; e < 24 * 12; e += 64) CB[e] = gP[(e % 24) + (size_t)(24 + e / 24) * N];   // old cols, rows < 24
+        {   // all loads first (twelve + five per thread in flight), then the stores to LDS
+            double rv[12], cv[5];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) { const int e = tid + 64 * q; rv[q] = (e < 12 * N) ? gP[(24 + e % 12) + (size_t)(e / 12) * N] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { const int e = tid + 64 * q; cv[q] = (e < 24 * 12) ? gP[(e % 24) + (size_t)(24 + e / 24) * N] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 12; ++q) { const int e = tid + 64 * q; if (e < 12 * N) RB[e] = rv[q]; }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { const int e = tid + 64 * q; if (e < 24 * 12) CB[e] = cv[q]; }     // old cols, rows < 24
+        }
         wave_sync();
         for (int e = tid; e < 12 * N; e += 64) {     // rows of state k+i against everything but itself: Fk * old rows
             const int r = e % 12, c = e / 12;
