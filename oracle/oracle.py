@@ -112,6 +112,7 @@ def lib():
         L.slko_accept_mahalanobis.argtypes = [C.c_double, C.c_int]
         L.slko_msckf_step_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, C.c_int,
                                             C.POINTER(C.c_uint)]
+        L.slko_usckf_step_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp]
     return _lib
 
 
@@ -427,6 +428,12 @@ def msckf_step_batch(k, m, steps, mean, P, u, feat, z, Q, R, gate=True):
     st = lib().slko_msckf_step_batch(B, k, m, steps, _p(mean), _p(P), _p(u), _p(feat), _p(z), _p(_colmajor(Q)),
                                      _p(_colmajor(R)), int(gate), out.ctypes.data_as(C.POINTER(C.c_uint)))
     return st, out
+
+
+def usckf_step_batch(nfk, nfkl, steps, mean, P, u, z, Q, R):
+    """In-place batch of `steps` x (Usckf predict + update), constant-velocity / relative-transform models."""
+    return lib().slko_usckf_step_batch(mean.shape[0], nfk, nfkl, steps, _p(mean), _p(P), _p(u), _p(z), _p(_colmajor(Q)),
+                                       _p(_colmajor(R)))
 
 
 # ---------------------------------------------------------------- f3 / f4 batch helpers

@@ -1229,6 +1229,34 @@ int slko_msckf_step_batch(int B, int k, int m, int steps, double *mean, double *
     return status;
 }
 
+/* B independent Usckf filters (N = 36 + nfk + nfkl), `steps` x (predict with the constant-velocity model of
+ * test/UsckfUnitTest.cpp:34-49 + update with the relative-transform model :62-86, no gate as in Usckf.hpp:249).
+ * u [B][7] = velocity[3] angular_velocity[3] dt; z [B][nfk].  CPU-baseline timing of bench.py --filter usckf. */
+int slko_usckf_step_batch(int B, int nfk, int nfkl, int steps, double *mean, double *P,
+                          const double *u, const double *z, const double *Q, const double *R)
+{
+    slko_layout lay = {SLKO_AUGMENTED, 0, nfk, nfkl};
+    int N = slko_dof(&lay), nq = slko_storage(&lay);
+    int status = 0;
+    for (int b = 0; b < B; ++b) {
+        slko_usckf f;
+        memset(&f, 0, sizeof(f));
+        f.lay = lay;
+        f.mean = mean + (size_t)b * nq;
+        f.P = P + (size_t)b * N * N;
+        slko_const_velocity cv;
+        memcpy(cv.velocity, u + (size_t)b * 7, sizeof(double) * 3);
+        memcpy(cv.angular_velocity, u + (size_t)b * 7 + 3, sizeof(double) * 3);
+        cv.dt = u[(size_t)b * 7 + 6];
+        for (int s = 0; s < steps; ++s) {
+            int acc = 0;
+            status |= slko_usckf_predict(&f, slko_pm_const_velocity, &cv, Q);
+            status |= slko_usckf_update(&f, z + (size_t)b * nfk, nfk, slko_mm_vo_relative, NULL, R, 0, &acc);
+        }
+    }
+    return status;
+}
+
 /* ====================================================================== */
 /* TransformWithUncertainty (src/core/Transform.cpp) and the pose legs of */
 /* DeadReckon::updatePose (src/core/DeadReckon.hpp:129-239, :306-330)     */

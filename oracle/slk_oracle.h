@@ -157,6 +157,11 @@ int slko_msckf_step_batch(int B, int k, int m, int steps, double *mean, double *
                           const double *u, const double *feat, const double *z,
                           const double *Q, const double *R, int gate, unsigned *outliers);
 
+/* same for B Usckf filters: constant-velocity process model + relative-transform measurement model, u [B][7],
+ * z [B][nfk], no gate */
+int slko_usckf_step_batch(int B, int nfk, int nfkl, int steps, double *mean, double *P,
+                          const double *u, const double *z, const double *Q, const double *R);
+
 #ifdef __cplusplus
 }
 #endif

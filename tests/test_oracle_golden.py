@@ -97,6 +97,18 @@ def test_usckf_spd_golden_and_np_crosscheck():
         assert np.abs(o.boxminus(f.lay, gnp.mean, g["mean"][b])).max() <= TOL
 
 
+def test_usckf_batch_driver_equals_the_golden_objects():
+    # slko_usckf_step_batch (the CPU-baseline leg of `bench.py --filter usckf`) is the same two calls per step
+    g = np.load(os.path.join(G, "usckf_spd.npz"))
+    s = sc.synthetic_usckf(4)
+    mean, P = s["mean"].copy(), np.ascontiguousarray(np.transpose(s["P"], (0, 2, 1))).reshape(4, -1)
+    assert o.usckf_step_batch(3, 9, 2, mean, P, s["u"], s["z"], s["Q"], s["R"]) == 0
+    lay = o.layout(o.AUGMENTED, 0, 3, 9)
+    for b in range(4):
+        assert rel(P[b].reshape(48, 48).T, g["P"][b]) <= TOL
+        assert np.abs(o.boxminus(lay, mean[b], g["mean"][b])).max() <= TOL
+
+
 def test_dead_reckon_golden_and_np_crosscheck():
     # DeadReckon::updatePose delta pose (src/core/DeadReckon.hpp:129-239, updateAttitude :246-286) and two
     # Msckf predicts driven by it (SLK_PM_DEAD_RECKON)
