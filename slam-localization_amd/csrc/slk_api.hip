@@ -249,7 +249,11 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
         if (rc) return rc;
         a.wsL = f->ws_L.p;
         a.wsfail = reinterpret_cast<int *>(f->ws_DR.p);
-        const size_t lds = (size_t)cv.total * sizeof(double);
+        size_t lds = (size_t)cv.total * sizeof(double);
+        if (HasFastStep<NT, NTHREADS, KST, MST>::value) {       // the exact-shape fast path carves LDS its own way
+            const size_t fl = (size_t)fast_step_lds_doubles(a.lay.k) * sizeof(double);
+            if (fl > lds) lds = fl;
+        }
         auto kern = msckf_step_kernel<NT, NTHREADS, KST, MST>;
         rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), f->cfg.device, lds);
         if (rc) return rc;

@@ -812,8 +812,13 @@ __device__ __forceinline__ double wave_inclusive_scan(double x)
     x += dpp_mov_f64<0x112, 0xf>(x);     // row_shr:2
     x += dpp_mov_f64<0x114, 0xf>(x);     // row_shr:4
     x += dpp_mov_f64<0x118, 0xf>(x);     // row_shr:8
-    x += dpp_mov_f64<0x142, 0xa>(x);     // row_bcast:15 into rows 1 and 3
-    x += dpp_mov_f64<0x143, 0xc>(x);     // row_bcast:31 into rows 2 and 3
+    // (the two cross-row steps move with a full row mask and add under a lane predicate: a partial row mask needs its
+    // destination pre-zeroed, and the scheduler hoists those zeros of all 36 scans of ldm_prefix -- 100+ registers)
+    const int ln = __lane_id();
+    const double t15 = dpp_mov_f64<0x142, 0xf>(x);     // row_bcast:15: last lane of the previous row
+    if (ln & 16) x += t15;                               // rows 1 and 3
+    const double t31 = dpp_mov_f64<0x143, 0xf>(x);     // row_bcast:31: lane 31
+    if (ln & 32) x += t31;                               // rows 2 and 3
     return x;
 }
 
@@ -1711,11 +1716,23 @@ struct MfmaTiles32 {
 // KST >= 0: the number of sensor-pose clones is a compile-time constant (exact-shape instantiation: the layout and
 // packed-index arithmetic fold); KST < 0: taken from the arguments.
 // MST > 0: the number of measurement rows is a compile-time constant too (every LDS offset of the carve folds).
+// exact-shape fast path of the update + applyDelta (slk_step_fast.hpp, included at the end of this file): k = 4 .. 8 clones,
+// m = 8 rows; returns false -- before its first global write -- whenever the general body below has to run instead
+template <int K> __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem);
+template <int NT, int NTHREADS, int KST, int MST> struct HasFastStep {
+    static constexpr bool value = KST >= 4 && KST <= 8 && MST == 8 && NTHREADS == 256 && NT == (12 + 6 * KST + 15) / 16;
+};
+
 template <int NT, int NTHREADS, int KST = -1, int MST = 0>
 __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? SLK_WGS : ((NT >= 5 && NT <= 8) ? 2 : (NT <= 2 ? 4 : 1)))) void msckf_step_kernel(KArgs a)
 {
     constexpr bool BIG = NT > 4;                           // large state (N > 64): factor + rotation store in the global workspace
     extern __shared__ __attribute__((aligned(16))) double smem[];
+#ifndef SLK_NO_FAST_STEP
+    if constexpr (HasFastStep<NT, NTHREADS, KST, MST>::value) {
+        if (!a.do_predict && a.do_update && msckf_step_fast<KST>(a, smem)) return;
+    }
+#endif
     constexpr int NW = NTHREADS / 64;
     constexpr int GD = Grid<NTHREADS>::GD;
     constexpr int SDN = (16 * NT + GD - 1) / GD;          // Cholesky register slots per dimension
@@ -2943,3 +2960,5 @@ __global__ void selftest_mfma_kernel(const double *Amat /*16x4 row-major*/, cons
 #endif
 
 } // namespace slk
+
+#include "slk_step_fast.hpp"
