@@ -66,8 +66,10 @@ struct slk_filter {
     Stage st_u, st_Q, st_mp, st_z, st_R, st_X, st_Z, st_tmpP, st_tmpM;
     Stage ws_L, ws_DR;            // large-state workspaces (N > 80), allocated on first use
     Stage ws_ekf;                 // EKF update workspace, allocated on first use
-    unsigned long long *d_rtab = nullptr;   // Msckf rotation-item descriptors of the current layout
-    int rtab_k = -1;
+    // Msckf rotation-item descriptors, one table per window length k the handle has run (a sliding window alternates
+    // between k and k + 1: the tables stay, so the steady state allocates and synchronises nothing)
+    struct Rtab { unsigned long long *dev = nullptr; std::vector<unsigned long long> host; };
+    std::map<int, Rtab> rtabs;
     hipEvent_t ev0, ev1;
     int rebuild_prec = 0;
 };
@@ -161,7 +163,7 @@ void slk_destroy(slk_filter *f)
     Stage *st[] = {&f->st_u, &f->st_Q, &f->st_mp, &f->st_z, &f->st_R, &f->st_X, &f->st_Z, &f->st_tmpP, &f->st_tmpM,
                    &f->ws_L, &f->ws_DR, &f->ws_ekf};
     for (Stage *s : st) if (s->p) (void)hipFree(s->p);
-    if (f->d_rtab) (void)hipFree(f->d_rtab);
+    for (auto &kv : f->rtabs) if (kv.second.dev) (void)hipFree(kv.second.dev);
     if (f->d_mean) (void)hipFree(f->d_mean);
     if (f->d_P) (void)hipFree(f->d_P);
     if (f->d_mean_alt) (void)hipFree(f->d_mean_alt);
@@ -229,17 +231,16 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
     KArgs a = a0;
     constexpr bool BIG = NT > 4;
     Carve cv = carve_step(a.lay, a.m, NT, BIG, a.rebuild_prec);
-    if (f->rtab_k != a.lay.k) {                 // layout changed (first launch, slk_msckf_resize): new descriptor table
-        std::vector<unsigned long long> tab((size_t)cv.W);
-        for (int w = 0; w < cv.W; ++w) tab[w] = rot_item_descriptor(a.lay.N, w);
-        if (f->d_rtab) HIPCHECK(hipFree(f->d_rtab));
-        f->d_rtab = nullptr; f->rtab_k = -1;
-        HIPCHECK(hipMalloc(&f->d_rtab, tab.size() * sizeof(unsigned long long)));
-        HIPCHECK(hipMemcpyAsync(f->d_rtab, tab.data(), tab.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, f->stream));
-        HIPCHECK(hipStreamSynchronize(f->stream));
-        f->rtab_k = a.lay.k;
+    {
+        slk_filter::Rtab &rt = f->rtabs[a.lay.k];
+        if (!rt.dev) {                             // first step at this window length: build the table, copy it on the stream
+            rt.host.resize((size_t)cv.W);          // (the host copy lives as long as the handle: the copy needs no wait)
+            for (int w = 0; w < cv.W; ++w) rt.host[w] = rot_item_descriptor(a.lay.N, w);
+            HIPCHECK(hipMalloc(&rt.dev, rt.host.size() * sizeof(unsigned long long)));
+            HIPCHECK(hipMemcpyAsync(rt.dev, rt.host.data(), rt.host.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, f->stream));
+        }
+        a.rtab = rt.dev;
     }
-    a.rtab = f->d_rtab;
     if constexpr (NT >= 3 && NT <= 4) {
         // Three launches per step: predict (one wave per filter), the first factorisation (its own residency, the packed
         // factor handed over through a workspace), update + applyDelta.

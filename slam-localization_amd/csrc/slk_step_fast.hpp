@@ -24,6 +24,13 @@
 // first global write and the general body runs instead.
 #pragma once
 // (included at the end of slk_kernels.hpp: uses its helpers)
+#ifdef SLK_STAMPS
+#define SLK_FSTAMP(i) do { SLK_STAMP_NR(i); if (a.stop > 0 && a.stop == (i)) return true; } while (0)
+#define SLK_WSTAMP(w, i) do { if (tid == 64 * (w) && a.dbg) a.dbg[(size_t)bidx * 32 + (i)] = clock64(); } while (0)
+#else
+#define SLK_FSTAMP(i) do { } while (0)
+#define SLK_WSTAMP(w, i) do { } while (0)
+#endif
 
 namespace slk {
 
@@ -185,6 +192,113 @@ __device__ __forceinline__ bool so3_log_tab(const double *T, const Quat (&q)[NV]
     return ok;
 }
 
+// exclusive prefix sums over the lanes (columns) of the entries E0 .. E0 + CNT - 1 of the packed lower triangle of a a^T
+template <int E0, int CNT>
+__device__ __forceinline__ void fast_scan_entries(const double (&av)[8], double (&G)[20])
+{
+#pragma unroll
+    for (int e = 0; e < CNT; ++e) {
+        constexpr int dummy = 0; (void)dummy;
+        const int q = E0 + e;
+        const int r = (q >= 1) + (q >= 3) + (q >= 6) + (q >= 10) + (q >= 15) + (q >= 21) + (q >= 28), cc = q - r * (r + 1) / 2;
+        const double pr = av[r] * av[cc];
+        G[e] = wave_inclusive_scan(pr) - pr;
+    }
+}
+
+// (block, column) pairs of the mean loop, tabulated at compile time: one 64-bit word per pair
+//   low dword : bits 0-12 / 13-25 offsets (doubles, from the start of LDS) of L'(toff, j) / L'(toff + 1, j) (an always-zero
+//               element where the tile is not stored), 26-29 the SO(3) block, 30-31 1 / 2 = the odd part of component 0 goes
+//               to str[15] / str[31] (row 15's columns 16 / 17, whose tile (0, 1) is not stored)
+//   high dword: bits 0-12 offset of L'(toff + 2, j), 13-23 offset of component 0 in E^
+template <int K> struct FastPairTable {
+    unsigned long long v[FastShape<K>::NP];
+    constexpr FastPairTable() : v{}
+    {
+        int p = 0;
+        for (int b = 0; b <= K; ++b) {
+            const int to = b ? 9 + 6 * b : 3;
+            for (int j = 0; j < to + 3; ++j, ++p) {
+                unsigned long long a[3] = {0, 0, 0};
+                for (int cc = 0; cc < 3; ++cc) {
+                    const int t = to + cc, I = t >> 4, Jc = j >> 4;
+                    a[cc] = (unsigned long long)(FastShape<K>::oLt + (Jc <= I ? (I * (I + 1) / 2 + Jc) * 256 + (j & 15) * 16 + (t & 15) : 16));
+                }
+                const int rho = 3 * b;
+                const unsigned long long e0 = (unsigned long long)(((j >> 2) * 2 + (rho >> 4)) * 64 + (j & 3) * 16 + (rho & 15));
+                const unsigned long long sd = (b == 1 && j >= 16) ? (unsigned long long)(j - 15) : 0ull;
+                v[p] = a[0] | (a[1] << 13) | ((unsigned long long)b << 26) | (sd << 30) | (a[2] << 32) | (e0 << 45);
+            }
+        }
+    }
+};
+template <int K> struct FastPairTableHolder { static __device__ const FastPairTable<K> tab; };
+template <int K> __device__ const FastPairTable<K> FastPairTableHolder<K>::tab = FastPairTable<K>();
+
+// ldm_columns (slk_kernels.hpp) with the column's deviations a_j = 1/2 dZ_j fetched from LDS where they are used instead of
+// held in sixteen registers beside the 36 prefix sums: lane j = column j, Gf = prefix sums, Sm = S (8 x 8), kept = rows
+// that survived the gate.  Writes Wb[bw_idx(j, :)] = 1/2 w~_j and mdiag[j] = sqrt(d_j); false if Pk - K S K^T is not
+// positive definite.
+#define SLK_G(r, c) Gf[(r) * ((r) + 1) / 2 + (c)]
+__device__ __forceinline__ bool fast_ldm_columns(double (&Gf)[36], const double *dZi, const double *Sm, unsigned kept, int lane, int N,
+                                                 double *Wb, double *mdiag)
+{
+    const bool live = lane < N;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const bool kr = (kept >> r) & 1u;
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+            const bool in = kr && ((kept >> c) & 1u);
+            const double sv = Sm[in ? r + 8 * c : 0];
+            SLK_G(r, c) = in ? sv - SLK_G(r, c) : ((r == c) ? 1.0 : 0.0);
+        }
+    }
+    // T_j = R R^T in place (R lower, its diagonal kept as reciprocals), y = R^-1 b, d = 1 - |y|^2, w = -R^-T y / sqrt(d)
+    double y[8];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double d = SLK_G(j, j);
+#pragma unroll
+        for (int p = 0; p < j; ++p) d = fma(-SLK_G(j, p), SLK_G(j, p), d);
+        ok = ok && (d > 0.0);
+        double sq, rs;
+        rsqrt_pivot(d, sq, rs);
+        SLK_G(j, j) = rs;
+#pragma unroll
+        for (int i = j + 1; i < 8; ++i) {
+            double v = SLK_G(i, j);
+#pragma unroll
+            for (int p = 0; p < j; ++p) v = fma(-SLK_G(i, p), SLK_G(j, p), v);
+            SLK_G(i, j) = v * rs;
+        }
+        const double aj = dZi[(j >> 1) * 128 + 2 * lane + (j & 1)];
+        double sacc = ((kept >> j) & 1u) ? 0.5 * aj : 0.0;
+#pragma unroll
+        for (int p = 0; p < j; ++p) sacc = fma(-SLK_G(j, p), y[p], sacc);
+        y[j] = sacc * rs;
+    }
+    double dj = 1.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) dj = fma(-y[c], y[c], dj);
+    ok = ok && (dj > 0.0);
+    double sqd, rsd;
+    rsqrt_pivot(dj, sqd, rsd);
+    const double sc = -0.5 * rsd;
+#pragma unroll
+    for (int c = 7; c >= 0; --c) {                   // w overwrites y from the back
+        double sacc = y[c];
+#pragma unroll
+        for (int p = c + 1; p < 8; ++p) sacc = fma(-SLK_G(p, c), y[p], sacc);
+        y[c] = sacc * SLK_G(c, c);
+        Wb[bw_idx(lane, c)] = live ? y[c] * sc : 0.0;
+    }
+    mdiag[lane] = live ? sqd : 1.0;
+    return __all(ok) != 0;
+}
+#undef SLK_G
+
 // L <- L M on the matrix cores, tiled factor (see ldm_product in slk_kernels.hpp for the algebra).  JB = tile column of the
 // last column any measurement row depends on: beyond it M is the identity (dZ rows are exactly zero), those blocks are
 // skipped.  fill() runs between the two barriers (everything but the factor is dead there).
@@ -322,7 +436,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
 {
     using F = FastShape<K>;
     constexpr int N = F::N, Nq = F::Nq, S = F::S, NSO3 = F::NSO3, NT = F::NT, NKS = F::NKS, NROT = F::NROT;
-    constexpr int NP = F::NP, NIT = F::NIT, RND = F::RND;
+    constexpr int NP = F::NP;
     if (a.mm != SLK_MM_FEATURE_PROJ || a.gate == 2 || a.emit != 0 || a.rebuild_prec != 0 || !a.mp || a.m != 8 || !a.wsfail) return false;
     const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -336,26 +450,12 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
     const double *gmean = a.mean + (size_t)bidx * Nq;
     const double *gP = a.P + (size_t)bidx * N * N;
     const double *mp = a.mp + (size_t)bidx * a.mp_stride;
-    if (a.wsfail[bidx] >= 0) return false;                      // the first factorisation failed (status: general body)
     SLK_STAMP_NR(0);
 
-    // ---- phase 0: mean, tiled factor, small arrays; pose indices and the rotation-column bound (Msckf.hpp:407-413)
-    int jmax = 0;
-    {
-        bool ok = true;
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const double cf = mp[4 * f + 3];
-            ok = ok && (cf >= 0.0) && (cf <= (double)K);
-            const int cp = (int)cf, tp = cp ? 6 + 6 * cp : 0;
-            jmax = (tp + 5 > jmax) ? tp + 5 : jmax;
-        }
-        if (!ok) return false;                                  // pose index out of range: SLK_ST_BAD_INDEX by the general body
-    }
-    for (int e = tid; e < Nq; e += 256) mu[e] = gmean[e];
-    if (tid < 64) { str[tid] = 0.0; pd[tid] = 0.0; ints[tid] = 0; }
-    if (tid < 32) { d0[tid] = 0.0; md32[tid] = 0.0; }
-    if (tid >= 64 && tid < 90) T[tid - 64] = fast_series_table[tid - 64];
+    // ---- phase 0: mean, tiled factor, small arrays.  Every global load is issued before the first use; the conditions that
+    // hand the filter to the general body -- failed first factorisation, pose index out of range (SLK_ST_BAD_INDEX there),
+    // a rotation column that may exceed pi (Msckf.hpp:407-413: covXZ = L A would not hold) -- meet in one barrier
+    int jmax = 0, bad;
     {
         const double *gL = a.wsL + (size_t)bidx * pk_size(N);
         const int t = lane, It = t >> 4;
@@ -367,6 +467,25 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             const bool in = j < N && t >= j && t < N;
             v[u] = gL[in ? pkcol(N, j) + t : 0];
         }
+        const double mu0 = (tid < Nq) ? gmean[tid] : 0.0;
+        const int t0 = (tid && tid < NSO3) ? 9 + 6 * tid : 3;
+        const double pdg = gP[t0 * (N + 1)] + gP[(t0 + 1) * (N + 1)] + gP[(t0 + 2) * (N + 1)];
+        const double tabv = fast_series_table[tid < 26 ? tid : 25];
+        bad = a.wsfail[bidx] >= 0;
+        bool ok = true;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const double cf = mp[4 * f + 3];
+            ok = ok && (cf >= 0.0) && (cf <= (double)K);
+            const int cp = ok ? (int)cf : 0, tp = cp ? 6 + 6 * cp : 0;
+            jmax = (tp + 5 > jmax) ? tp + 5 : jmax;
+        }
+        bad |= !ok;
+        if (tid < NSO3) bad |= !(pdg < 9.869604401089358);
+        if (tid < Nq) mu[tid] = mu0;
+        if (tid < 64) { str[tid] = 0.0; pd[tid] = 0.0; ints[tid] = 0; }
+        if (tid < 32) { d0[tid] = 0.0; md32[tid] = 0.0; }
+        if (tid < 26) T[tid] = tabv;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int j = 4 * u + wave;
@@ -374,16 +493,8 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             if ((u >> 2) < NT && It >= (u >> 2) && It < NT) Lt[lbase + (u >> 2) * 256 + (u & 3) * 64] = in ? v[u] : 0.0;
         }
     }
-    {
-        int wrapf = 0;
-        if (tid < NSO3) {
-            const int t0 = tid ? 9 + 6 * tid : 3;
-            const double s = gP[t0 * (N + 1)] + gP[(t0 + 1) * (N + 1)] + gP[(t0 + 2) * (N + 1)];
-            wrapf = !(s < 9.869604401089358);
-        }
-        if (__syncthreads_or(wrapf)) return false;              // a rotation column may exceed pi: covXZ = L A does not hold
-    }
-    SLK_STAMP_NR(3);
+    if (__syncthreads_or(bad)) return false;
+    SLK_FSTAMP(3);
 
     // ---- phase 1: Z = h(X) (Msckf.hpp:231-232), one wave per feature, lane j = the sigma pair of column j
     {
@@ -431,10 +542,11 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
         }
     }
     __syncthreads();
-    SLK_STAMP_NR(4);
+    SLK_FSTAMP(4);
 
-    // ---- phase 2: S = 1/2 sum (Z_i - mean_z)(Z_i - mean_z)^T + R (:238) on wave 0
-    if (wave == 0) {
+    // ---- phase 2: S = 1/2 sum (Z_i - mean_z)(Z_i - mean_z)^T + R (:238) on wave 1
+    double Gs[20];
+    if (wave == 1) {
         d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -447,9 +559,18 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
         const double *R = a.R + (size_t)bidx * a.r_stride;
         const int row = lane & 7, col = lane >> 3;
         Sm[lane] = 0.5 * ((tmpS[lane] + tmpS[64 + lane]) - (double)S * dz0[row] * dz0[col]) + R[lane];
+    } else if (wave >= 2) {
+        // prefix sums over the columns of a a^T (ldm_prefix: the 36 entries of the packed lower triangle, lane = column),
+        // the first 16 by wave 2, the others by wave 3: one wave's 36 scans were the longest serial stretch of the step
+        double av[8];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) av[cc] = 0.5 * dZi[(cc >> 1) * 128 + 2 * lane + (cc & 1)];
+        if (wave == 2) fast_scan_entries<0, 16>(av, Gs);
+        else fast_scan_entries<16, 20>(av, Gs);
+        SLK_WSTAMP(3, 21);
     }
     __syncthreads();
-    SLK_STAMP_NR(6);
+    SLK_FSTAMP(6);
 
     // ---- gate: removeOutliers (:723-754) with the shifted second erase (:741-744); every wave takes the same decisions
     unsigned kept = 0xffu, nout = 0u;
@@ -489,33 +610,16 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
         }
     }
     if (kept == 0u) return false;                               // every block rejected (:250): status by the general body
-    SLK_STAMP_NR(7);
+    SLK_FSTAMP(7);
 
     // ---- gain side.  wave 3: columns of the factor update.  wave 0: x = S^-1 nu over the surviving rows (rejected rows
     // as identity rows), b = 1/2 dZ x, delta = K nu = L b (:257, :263), then the reference point of the mean loop.
-    if (wave == 3) {
-        // (prefix sums and columns in ONE branch: their 88 live registers must not span a barrier or the gate)
-        double Gf[36], av[8];
+    if (wave == 2) {
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) av[cc] = 0.5 * dZi[(cc >> 1) * 128 + 2 * lane + (cc & 1)];
-        // prefix sums over the columns (ldm_prefix); the first 16 of the 36 wait in LDS (the dead Yp rows) while the others
-        // are scanned: all 36 next to the operands and the scans in flight do not fit the 128 registers
-#pragma unroll
-        for (int e = 0; e < 36; ++e) {
-            const int r = (e >= 1) + (e >= 3) + (e >= 6) + (e >= 10) + (e >= 15) + (e >= 21) + (e >= 28), cc = e - r * (r + 1) / 2;
-            const double pr = av[r] * av[cc];
-            const double ex = wave_inclusive_scan(pr) - pr;
-            if (e < 16) Yp[e * 64 + lane] = ex; else Gf[e] = ex;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Gf[e] = Yp[e * 64 + lane];
-        mdiag[lane] = 1.0;
-        const bool pdok = ldm_columns(Gf, av, Sm, 8, kept, lane, N, Wb, mdiag);
-        if (!pdok && lane == 0) ints[48] = 1;
+        for (int e = 0; e < 16; ++e) Yp[e * 64 + lane] = Gs[e];        // (the Yp rows are dead: S is done)
     }
-#ifndef SLK_EXP_B
-    else if (wave == 0) {
+    __syncthreads();
+    if (wave == 0) {
         double gg[8][8], gi[8], y[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -555,6 +659,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             y[cc] = s * gi[cc];
         }
         if (!spd && lane == 0) ints[49] = 1;
+        SLK_WSTAMP(0, 24);
         double bj = 0.0;
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) bj = fma(dZi[(cc >> 1) * 128 + 2 * lane + (cc & 1)], y[cc], bj);
@@ -590,91 +695,108 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             stq(ref + so, qr);
             stq(cq + 4 * lane, qmul(qconj(qr), qm));
         }
+        SLK_WSTAMP(0, 25);
     }
-#endif
+    else if (wave == 3) {
+        SLK_WSTAMP(3, 22);
+        double Gf[36];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Gf[e] = Yp[e * 64 + lane];
+#pragma unroll
+        for (int e = 16; e < 36; ++e) Gf[e] = Gs[e - 16];
+        const bool pdok = fast_ldm_columns(Gf, dZi, Sm, kept, lane, N, Wb, mdiag);
+        if (!pdok && lane == 0) ints[48] = 1;
+        SLK_WSTAMP(3, 23);
+    }
     __syncthreads();
     if (ints[48] | ints[49]) return false;                      // indefinite downdate / non-SPD S: the general body decides
 #ifdef SLK_EXP_A
     return true;
 #endif
-    SLK_STAMP_NR(8);
+    SLK_FSTAMP(8);
 
     // ---- applyDelta's factor: L' = L chol(I - B B^T) (:262-263, :659-662)
+    unsigned long long pt0 = 0, pt1 = 0;                       // pair descriptors of the mean loop
     ldm_product_tiled<NT>(Lt, dZi, Wb, mdiag, lane, wave, jmax >> 4, [&]() {
+        pt0 = FastPairTableHolder<K>::tab.v[tid < NP ? tid : 0];
+        pt1 = FastPairTableHolder<K>::tab.v[(wave == 1 && 256 + lane < NP) ? 256 + lane : 0];
         for (int e = tid; e < NKS * 128; e += 256) Et[e] = 0.0;
     });
-    SLK_STAMP_NR(11);
+    SLK_FSTAMP(11);
 
-    // ---- manifold mean of the re-drawn sigma points (:664 -> :499-525) over (block, column) pairs
-    int aL[RND][3], aE[RND][3], aO0[RND], bb[RND];
-    bool val[RND], ctr[RND];
+    // ---- manifold mean of the re-drawn sigma points (:664 -> :499-525) over (block, column) pairs: round 0 on every wave,
+    // the pairs beyond 256 on wave 1, the centre points (one deviation each) on wave 2, the row sums on waves 2 / 3
+    constexpr int RP = (NP + 255) / 256;                         // rounds of pairs (2 for k >= 7)
+    int aL[RP][3], aE[RP][3], aO0[RP], bb[RP];
+    bool val[RP];
 #pragma unroll
-    for (int r = 0; r < RND; ++r) {
-        const int p = tid + 256 * r;
-        val[r] = p < NIT;
-        ctr[r] = p >= NP;
-        int b = 0;
-#pragma unroll
-        for (int q = 1; q <= K; ++q) b += (p >= 3 * q * q + 9 * q - 6) ? 1 : 0;
-        if (ctr[r]) b = val[r] ? p - NP : 0;
-        const int j = ctr[r] ? 0 : p - (b ? 3 * b * b + 9 * b - 6 : 0);
-        const int to = b ? 9 + 6 * b : 3;
+    for (int r = 0; r < RP; ++r) {
+        const unsigned long long w = r ? pt1 : pt0;
+        const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
+        val[r] = (r ? 256 + lane : tid) < NP && (r == 0 || wave == 1);
+        const int b = (lo >> 26) & 15, sd = lo >> 30, rho = 3 * b;
         bb[r] = b;
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-            const int t = to + cc, I = t >> 4, Jc = j >> 4, rho = 3 * b + cc;
-            const bool stored = Jc <= I && !ctr[r] && val[r];
-            aL[r][cc] = F::oLt + (stored ? (I * (I + 1) / 2 + Jc) * 256 + (j & 15) * 16 + (t & 15) : 16);
-            aE[r][cc] = ((j >> 2) * 2 + (rho >> 4)) * 64 + (j & 3) * 16 + (rho & 15);
-        }
-        // row 15 (block 1, component 0) has its columns 16 / 17 in tile (0, 1), which is not stored
-        aO0[r] = (b == 1 && j >= 16 && !ctr[r] && val[r]) ? F::oStr + (j - 16) * 16 + 15 : aL[r][0];
+        aL[r][0] = lo & 0x1fff; aL[r][1] = (lo >> 13) & 0x1fff; aL[r][2] = hi & 0x1fff;
+        aE[r][0] = (hi >> 13) & 0x7ff;
+        aE[r][1] = aE[r][0] + ((rho & 15) == 15 ? 49 : 1);       // (a component that crosses into the second 16 rows of E^)
+        aE[r][2] = aE[r][1] + (((rho + 1) & 15) == 15 ? 49 : 1);
+        aO0[r] = sd ? F::oStr + 16 * (int)sd - 1 : aL[r][0];
     }
-    double dpl[RND][3], dmi[RND][3];
+    double dpl[RP][3], dmi[RP][3], dc[3] = {0.0, 0.0, 0.0};
     int it = 0;
     for (;;) {
 #pragma unroll
-        for (int r = 0; r < RND; ++r) {
-            if (256 * r + 64 * wave >= NIT) continue;           // nothing for this wave in this round
+        for (int r = 0; r < RP; ++r) {
+            if (r == 0 ? 64 * wave >= NP : wave != 1) continue;  // nothing for this wave in this round
             const int b = bb[r], to = b ? 9 + 6 * b : 3;
             const double l0 = smem[aL[r][0]], l1 = smem[aL[r][1]], l2 = smem[aL[r][2]];
             const double e0 = delta[to], e1 = delta[to + 1], e2 = delta[to + 2];
             const Quat cb = ldq(cq + 4 * b);
-            {
-                const double rv[2][3] = {{e0 + l0, e1 + l1, e2 + l2}, {e0 - l0, e1 - l1, e2 - l2}};
-                Quat ex[2];
-                double dd[2][3];
-                bool ok = so3_exp_tab<2>(T, rv, ex);
-                ex[0] = qmul(cb, ex[0]);
-                ex[1] = qmul(cb, ex[1]);
-                ok = so3_log_tab<2>(T, ex, dd) && ok;
-                if (!__all(ok)) {                                // beyond the series' domains: the libm route
-                    const Dev3 a0 = so3_dev_slow(cb, rv[0][0], rv[0][1], rv[0][2]), a1 = so3_dev_slow(cb, rv[1][0], rv[1][1], rv[1][2]);
-                    dd[0][0] = a0.x; dd[0][1] = a0.y; dd[0][2] = a0.z;
-                    dd[1][0] = a1.x; dd[1][1] = a1.y; dd[1][2] = a1.z;
-                }
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc) { dpl[r][cc] = dd[0][cc]; dmi[r][cc] = dd[1][cc]; }
+            const double rv[2][3] = {{e0 + l0, e1 + l1, e2 + l2}, {e0 - l0, e1 - l1, e2 - l2}};
+            Quat ex[2];
+            double dd[2][3];
+            bool ok = so3_exp_tab<2>(T, rv, ex);
+            ex[0] = qmul(cb, ex[0]);
+            ex[1] = qmul(cb, ex[1]);
+            ok = so3_log_tab<2>(T, ex, dd) && ok;
+            if (!__all(ok)) {                                    // beyond the series' domains: the libm route
+                const Dev3 a0 = so3_dev_slow(cb, rv[0][0], rv[0][1], rv[0][2]), a1 = so3_dev_slow(cb, rv[1][0], rv[1][1], rv[1][2]);
+                dd[0][0] = a0.x; dd[0][1] = a0.y; dd[0][2] = a0.z;
+                dd[1][0] = a1.x; dd[1][1] = a1.y; dd[1][2] = a1.z;
             }
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) { dpl[r][cc] = dd[0][cc]; dmi[r][cc] = dd[1][cc]; }
             if (val[r]) {
-                if (ctr[r]) {
 #pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) d0[3 * b + cc] = dpl[r][cc];
-                } else {
-#pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) Et[aE[r][cc]] = 0.5 * (dpl[r][cc] + dmi[r][cc]);
-                }
+                for (int cc = 0; cc < 3; ++cc) Et[aE[r][cc]] = 0.5 * (dpl[r][cc] + dmi[r][cc]);
             }
+        }
+        if (wave == 2) {                                         // X_0 [-] ref per block
+            const int b = lane < NSO3 ? lane : 0, to = b ? 9 + 6 * b : 3;
+            const double rv[1][3] = {{delta[to], delta[to + 1], delta[to + 2]}};
+            const Quat cb = ldq(cq + 4 * b);
+            Quat ex[1];
+            double dd[1][3];
+            bool ok = so3_exp_tab<1>(T, rv, ex);
+            ex[0] = qmul(cb, ex[0]);
+            ok = so3_log_tab<1>(T, ex, dd) && ok;
+            if (!__all(ok)) {
+                const Dev3 a0 = so3_dev_slow(cb, rv[0][0], rv[0][1], rv[0][2]);
+                dd[0][0] = a0.x; dd[0][1] = a0.y; dd[0][2] = a0.z;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) { dc[cc] = dd[0][cc]; if (lane < NSO3) d0[3 * b + cc] = dc[cc]; }
         }
         __syncthreads();
         // mean_delta = sum_i (X_i [-] ref) / S (:507-509): the S - 2 (toff + 3) points beyond the block's columns equal X_0
-        if (wave < 2) {
+        if (wave >= 2) {
+            const int hr = wave - 2;
             double s = 0.0;
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) s += Et[(ks * 2 + wave) * 64 + lane];
+            for (int ks = 0; ks < NKS; ++ks) s += Et[(ks * 2 + hr) * 64 + lane];
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
-            const int rho = 16 * wave + c16;
+            const int rho = 16 * hr + c16;
             if (g4 == 0 && rho < NROT) {
                 const int b = rho / 3, np = b ? 12 + 6 * b : 6;
                 md32[rho] = (2.0 * s + (double)(S - 2 * np) * d0[rho]) / (double)S;
@@ -696,17 +818,13 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
         if (++it >= 64) return false;                            // (nothing has been written yet: the general body starts over)
         __syncthreads();
     }
-    SLK_STAMP_NR(12);
+    SLK_FSTAMP(12);
     SLK_NOTE(20, it + 1);
     // The loop leaves with |mean_delta| <= 1e-6: deviations against the FINAL mean by the first-order correction
     //     d' = d - Jl^-1(d) m,  Jl^-1(d) m = m - 1/2 d x m + (1/12 + |d|^2 / 720) d x (d x m)       (slk_kernels.hpp)
     // then the odd parts into the rotation rows of the factor array, the even parts minus the centre into E^.
-#pragma unroll
-    for (int r = 0; r < RND; ++r) {
-        if (256 * r + 64 * wave >= NIT) continue;
-        const int b = bb[r];
-        const double m0 = md32[3 * b], m1 = md32[3 * b + 1], m2 = md32[3 * b + 2];
-        auto fix = [&](double &x, double &y, double &z) __attribute__((always_inline)) {
+    {
+        auto fix = [&](double &x, double &y, double &z, double m0, double m1, double m2) __attribute__((always_inline)) {
             const double cx = y * m2 - z * m1, cy = z * m0 - x * m2, cz = x * m1 - y * m0;      // d x m
             const double ax = y * cz - z * cy, ay = z * cx - x * cz, az = x * cy - y * cx;      // d x (d x m)
             const double a12 = 1.0 / 12.0 + (x * x + y * y + z * z) * (1.0 / 720.0);
@@ -714,14 +832,16 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             y = y - m1 + 0.5 * cy - a12 * ay;
             z = z - m2 + 0.5 * cz - a12 * az;
         };
-        double c0 = d0[3 * b], c1 = d0[3 * b + 1], c2 = d0[3 * b + 2];
-        fix(c0, c1, c2);
-        fix(dpl[r][0], dpl[r][1], dpl[r][2]);
-        fix(dmi[r][0], dmi[r][1], dmi[r][2]);
-        if (val[r]) {
-            if (ctr[r]) {
-                pd[32 + 3 * b] = c0; pd[32 + 3 * b + 1] = c1; pd[32 + 3 * b + 2] = c2;
-            } else {
+#pragma unroll
+        for (int r = 0; r < RP; ++r) {
+            if (r == 0 ? 64 * wave >= NP : wave != 1) continue;
+            const int b = bb[r];
+            const double m0 = md32[3 * b], m1 = md32[3 * b + 1], m2 = md32[3 * b + 2];
+            double c0 = d0[3 * b], c1 = d0[3 * b + 1], c2 = d0[3 * b + 2];
+            fix(c0, c1, c2, m0, m1, m2);
+            fix(dpl[r][0], dpl[r][1], dpl[r][2], m0, m1, m2);
+            fix(dmi[r][0], dmi[r][1], dmi[r][2], m0, m1, m2);
+            if (val[r]) {
                 smem[aO0[r]] = 0.5 * (dpl[r][0] - dmi[r][0]);
                 smem[aL[r][1]] = 0.5 * (dpl[r][1] - dmi[r][1]);
                 smem[aL[r][2]] = 0.5 * (dpl[r][2] - dmi[r][2]);
@@ -729,6 +849,10 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
                 Et[aE[r][1]] = 0.5 * (dpl[r][1] + dmi[r][1]) - c1;
                 Et[aE[r][2]] = 0.5 * (dpl[r][2] + dmi[r][2]) - c2;
             }
+        }
+        if (wave == 2 && lane < NSO3) {
+            fix(dc[0], dc[1], dc[2], md32[3 * lane], md32[3 * lane + 1], md32[3 * lane + 2]);
+            pd[32 + 3 * lane] = dc[0]; pd[32 + 3 * lane + 1] = dc[1]; pd[32 + 3 * lane + 2] = dc[2];
         }
     }
     // the new mean (:664): no fallback beyond this point
@@ -745,16 +869,17 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
     }
     if (tid == 0) a.outliers[bidx] = nout;
     __syncthreads();
-    SLK_STAMP_NR(13);
+    SLK_FSTAMP(13);
 
-    // ---- P+ (:665 -> :574-589): p = sum_j e^_j + (N + 1/2) / 2 d0 by waves 0 / 1, the tile columns one per wave
-    if (wave < 2) {
+    // ---- P+ (:665 -> :574-589): p = sum_j e^_j + (N + 1/2) / 2 d0 by waves 2 / 3, the tile columns one per wave
+    if (wave >= 2) {
+        const int hr = wave - 2;
         double s = 0.0;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) s += Et[(ks * 2 + wave) * 64 + lane];
+        for (int ks = 0; ks < NKS; ++ks) s += Et[(ks * 2 + hr) * 64 + lane];
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
-        const int rho = 16 * wave + c16;
+        const int rho = 16 * hr + c16;
         if (g4 == 0 && rho < NROT) pd[rho] = s + (0.5 * ((double)N + 0.5)) * pd[32 + rho];
     }
     d4 acc[NT];
@@ -765,7 +890,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
     else if (wave == 2) fast_rebuild_col<K, 2>(Lt, Et, str, lane, acc);
     else if constexpr (NT > 3) fast_rebuild_col<K, 3>(Lt, Et, str, lane, acc);
     __syncthreads();                                             // factor and E^ are dead; p is complete
-    SLK_STAMP_NR(14);
+    SLK_FSTAMP(14);
     if (wave == 0) fast_store_col<K, 0>(pd, Lt, oP, lane, acc);
     else if (wave == 1) fast_store_col<K, 1>(pd, Lt, oP, lane, acc);
     else if (wave == 2) fast_store_col<K, 2>(pd, Lt, oP, lane, acc);

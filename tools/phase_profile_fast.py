@@ -46,6 +46,12 @@ def main():
         d = np.median(t[ok][:, i] - t[ok][:, prev])
         print(f"  {name:52s} {d:9.0f}  {100 * d / tot:5.1f} %")
         prev = i
+    x = t[ok]
+    if (x[:, 23] > 0).all():
+        m = lambda a, b: np.median(x[:, a] - x[:, b])
+        print(f"  wave 3: its 20 scans done {m(21, 4):.0f} after stamp 4 (S: {m(6, 4):.0f}); past the park barrier {m(22, 7):.0f} after the gate; "
+              f"parked sums + columns {m(23, 22):.0f}")
+        print(f"  wave 0: x = S^-1 nu {m(24, 7):.0f} after the gate; b, delta = L b, reference {m(25, 24):.0f}; waits for wave 3 {m(8, 25):.0f}")
 
 
 if __name__ == "__main__":

@@ -49,8 +49,14 @@ def main():
     ap.add_argument("--clones", type=int, default=8)
     ap.add_argument("--meas", type=int, default=8)
     ap.add_argument("--report", default=None)
+    ap.add_argument("--fast", action="store_true", help="stop points / phase names of the exact-shape fast path (slk_step_fast.hpp)")
     ap.add_argument("--lib", default=None, help="a stamps build made elsewhere (build.py --dev NAME --stamps), e.g. ab/NAME.so")
     args = ap.parse_args()
+    if args.fast:
+        global STOPS, NAMES
+        STOPS = [3, 4, 6, 8, 11, 12, 13, 14, 0]
+        NAMES = {3: "load", 4: "Z = h(X), zbar", 6: "S | scans", 8: "gate, x b delta | columns", 11: "factor update",
+                 12: "mean loop", 13: "correction, split", 14: "rebuild MFMA", 0: "rank-2, store"}
     if args.report:
         return report(args.report, args.batch)
     import torch
