@@ -19,6 +19,8 @@
 #include <cmath>
 #include <cstddef>
 #include <iostream>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace localization
@@ -53,6 +55,26 @@ namespace slk
     public:
         Matrix() : r_(0), c_(0) {}
         Matrix(int r, int c) : r_(r), c_(c), d_((std::size_t)r * c, 0.0) {}
+        /** from / to any other column-major matrix type with data() / rows() / cols() -- an Eigen::Matrix<double, 12, 12> of
+         *  a caller, say: what the reference hands out as SingleStateCovariance etc. converts into the caller's own type
+         *  (resized first if that type has resize(rows, cols); a fixed-size type must match) */
+        template <class M, class = typename std::enable_if<!std::is_base_of<Matrix, M>::value, decltype((void)std::declval<const M &>().data(),
+                  (void)std::declval<const M &>().rows(), (void)std::declval<const M &>().cols())>::type>
+        Matrix(const M &o) : r_((int)o.rows()), c_((int)o.cols()), d_(o.data(), o.data() + (std::size_t)o.rows() * o.cols()) {}
+        template <class M, class = typename std::enable_if<!std::is_base_of<Matrix, M>::value && !std::is_arithmetic<M>::value,
+                  decltype((void)std::declval<M &>().data(), (void)std::declval<const M &>().rows(), (void)std::declval<const M &>().cols())>::type>
+        operator M() const
+        {
+            M out;
+            resize_if_possible(out, r_, c_, 0);
+            assert((int)out.rows() == r_ && (int)out.cols() == c_);
+            std::copy(d_.begin(), d_.end(), out.data());
+            return out;
+        }
+    private:
+        template <class M> static auto resize_if_possible(M &m, int r, int c, int) -> decltype(m.resize(r, c), void()) { m.resize(r, c); }
+        template <class M> static void resize_if_possible(M &, int, int, long) {}
+    public:
         static Matrix Zero(int r, int c) { return Matrix(r, c); }
         static Matrix Identity(int r, int c) { Matrix m(r, c); for (int i = 0; i < r && i < c; ++i) m(i, i) = 1.0; return m; }
         void resize(int r, int c) { r_ = r; c_ = c; d_.assign((std::size_t)r * c, 0.0); }

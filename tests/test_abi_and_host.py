@@ -70,6 +70,8 @@ def test_cpp_header_facade_compiles_and_links(slk):
     import facade_build
     exe = facade_build.build()
     assert os.path.exists(exe)
+    # ... and a caller whose matrices / vectors are fixed-size types of its own (tests/cpp/foreign_matrix.cpp)
+    assert os.path.exists(facade_build.build("foreign_matrix"))
     hdr = open(os.path.join(ROOT, "include", "localization", "filters", "Usckf.hpp")).read()
     for name in ("enum CloningMode", "STATEK_I = 3", "class Usckf", "void cloning(int mode)", "setMeasurement(CloningMode mode",
                  "PkAugmentedState() const", "muSingleState(int state = STATEK_I)"):

@@ -122,7 +122,9 @@ def test_reference_process_model_and_significance_tests_through_facade(ref, tag)
     # the arbitrary callable really ran on the host: once per block it looked at (4 blocks, one rejected -> 4 calls)
     assert int(ref[f"ref_msckf_{tag}_mt_calls"][0, 0]) == (4 if tag == "c" else 0)
     for key in ("upd_P", "upd_mean"):
-        np.testing.assert_array_equal(ref[f"ref_msckf_{tag}_{key}"], ref[f"ref_msckf_a_{key}"])
+        # (a caller-side significance test goes through the general step kernel, the built-in gate through the exact-shape
+        # fast path: the same update in another operation order -- equal to rounding, not bit for bit)
+        np.testing.assert_allclose(ref[f"ref_msckf_{tag}_{key}"], ref[f"ref_msckf_a_{key}"], rtol=0, atol=1e-13)
 
 
 def test_nonconst_mustate_window_edit_through_facade(ref):
@@ -164,3 +166,35 @@ def test_reference_usckf_models_through_facade(ref):
         assert ref[f"ref_usckf_{tag}_check_ok"][0, 0] == 1 and ref[f"ref_usckf_{tag}_check_cov"][0, 0] <= 1e-10
     assert int(ref["ref_usckf_mt_mt_calls"][0, 0]) == 2
     assert ref["ref_usckf_rejected_unchanged"][0, 0] == 1
+
+
+def test_callers_own_matrix_types_through_facade():
+    """tests/cpp/foreign_matrix.cpp: the caller's matrices / vectors are fixed-size types of its own (standing in for
+    Eigen::Matrix<double, 12, 12> etc. of a Rock task), not slk::Matrix: constructor, predict's Q, update's z / R, the EKF's
+    H, setPk / setPkSingleState / setMeasurement take them, getPk / getPkSingleState / PkSingleState convert into them.
+    The same scenario on the facade's own types must print the same numbers, and the k = 8 update agrees with the oracle."""
+    import __graft_entry__ as ge
+    ge.build()
+    import facade_build
+    r = facade_build.run(name="foreign_matrix")
+    keys = [k[len("foreign_"):] for k in r if k.startswith("foreign_")]
+    assert len(keys) >= 19
+    for k in keys:
+        np.testing.assert_array_equal(r["foreign_" + k], r["own_" + k], err_msg=k)
+    assert r["foreign_k8_upd_P"].shape == (60, 60) and r["foreign_k8_P12"].shape == (12, 12)
+    np.testing.assert_array_equal(r["foreign_k8_P12"], r["foreign_k8_upd_P"][:12, :12])
+    assert int(r["foreign_k8_status"][0, 0]) == 0 and int(r["foreign_k2_status"][0, 0]) == 0
+    assert r["foreign_usckf_PkI"].shape == (12, 12)
+    # k = 8 against the oracle: two predicts with the delta-pose model, one update with four features
+    import scenarios as sc
+    s = sc.msckf_unit_test(8)
+    f = o.Msckf(8, s["mean"], s["P"])
+    pm = o.pm_delta_pose(s["dpos"], s["dquat"], s["velocity"], s["angular_velocity"])
+    for _ in range(2):
+        assert f.predict(pm, s["Q"]) == 0
+    feat = np.array([[0.5 * (j - 1.5), 0.3 * (1.5 - j), 5.0 + j, (j % 8) + 1] for j in range(4)])
+    z = np.array([v for j in range(4) for v in (0.1 * (j - 1.0) * 0.5, 0.05 * (j + 0.5) * 0.5)])
+    st, no = f.update(z, o.mm_feature_proj(feat), 0.01 * np.eye(8))
+    assert st == 0 and no == int(r["foreign_k8_outliers"][0, 0])
+    assert rel(r["foreign_k8_upd_P"], f.P) <= TOL
+    assert np.abs(o.boxminus(o.layout(o.MULTI, 8), r["foreign_k8_upd_mean"][:, 0], f.mean)).max() <= TOL
