@@ -62,6 +62,7 @@ namespace localization
         mutable bool mean_dirty, cov_dirty; /** the mirror holds something newer than the device **/
         mutable slk::Handle h;
         unsigned int last_outliers;
+        int host_status = 0;                /** status bits decided on the host (EKF update behind a caller-side test) **/
 
         /** push host-side edits (muState(), muSingleState(state), setPk, setPkSingleState) to the device */
         void sync_device() const
@@ -319,6 +320,14 @@ namespace localization
                     ++i;
                 }
             }
+            last_outliers = nout;
+            if (cnt == 0) return nout;                       // every block rejected: nothing is applied (Msckf.hpp:320)
+            if (cnt < N) {
+                // fewer rows than states survive: the reference's reduceDimension would index R.block(0, 0, N, N) out of
+                // range (:806).  Same outcome as with the built-in gate: the update is skipped, SLK_ST_EKF_ROWS is reported
+                host_status |= SLK_ST_EKF_ROWS;
+                return nout;
+            }
             std::vector<double> zs(cnt), zm(cnt), Hs((std::size_t)cnt * N), Rs((std::size_t)cnt * cnt);
             for (int r = 0; r < cnt; ++r) {
                 zs[r] = z[idx[r]]; zm[r] = mean_z[idx[r]];
@@ -390,7 +399,7 @@ namespace localization
         }
 
         /** per-filter numerical status bits of include/slk.h (the reference reports nothing) */
-        int status() { int s = 0; slk::check(slk_get_status(h.get(), &s, SLK_HOST), "slk_get_status"); return s; }
+        int status() { int s = 0; slk::check(slk_get_status(h.get(), &s, SLK_HOST), "slk_get_status"); return s | host_status; }
 
         /** chi-square gate of the reference (:844-905) */
         template <typename _ScalarType>

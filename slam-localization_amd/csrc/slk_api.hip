@@ -656,7 +656,7 @@ int slk_transform_compose(slk_filter *f, const double *t2, const double *cov2, c
         dt = f->st_tmpM.p;
         dc = cov_out ? f->st_tmpP.p : nullptr;
     }
-    hipLaunchKernelGGL(transform_compose_kernel, dim3((f->B + 127) / 128), dim3(128), 0, f->stream, f->B, d2, dc2, d1, dc1, dt, dc,
+    hipLaunchKernelGGL(transform_compose_kernel, dim3((f->B + 63) / 64), dim3(64), 0, f->stream, f->B, d2, dc2, d1, dc1, dt, dc,
                        additive);
     HIPCHECK(hipGetLastError());
     if (where == SLK_HOST) {
@@ -691,7 +691,7 @@ int slk_dead_reckon_pose(slk_filter *f, const double *u, int u_stride, const dou
         ddelta = delta ? f->st_Z.p : nullptr;
         HIPCHECK(hipMemcpyAsync(dpost, post, B * 49 * sizeof(double), hipMemcpyHostToDevice, f->stream));
     }
-    hipLaunchKernelGGL(dead_reckon_pose_kernel, dim3((f->B + 127) / 128), dim3(128), 0, f->stream, f->B, du, u_stride, dv, c_stride,
+    hipLaunchKernelGGL(dead_reckon_pose_kernel, dim3((f->B + 63) / 64), dim3(64), 0, f->stream, f->B, du, u_stride, dv, c_stride,
                        dp, dpost, ddelta, use_tf);
     HIPCHECK(hipGetLastError());
     if (where == SLK_HOST) {

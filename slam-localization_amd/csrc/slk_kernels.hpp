@@ -842,6 +842,7 @@ __device__ __forceinline__ void ldm_prefix(const double (&a)[8], double (&Gf)[36
         for (int c = 0; c <= r; ++c) {
             const double e = a[r] * a[c];
             SLK_G(r, c) = wave_inclusive_scan(e) - e;        // exclusive: sum over the lanes (columns) before this one
+            if (c == r) __builtin_amdgcn_sched_barrier(0);   // (one row of scans in flight at a time: registers)
         }
 }
 
@@ -1724,7 +1725,9 @@ template <int NT, int NTHREADS, int KST, int MST> struct HasFastStep {
 };
 
 template <int NT, int NTHREADS, int KST = -1, int MST = 0>
-__global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? SLK_WGS : ((NT >= 5 && NT <= 8) ? 2 : (NT <= 2 ? 4 : 1)))) void msckf_step_kernel(KArgs a)
+// (register budget: the exact-shape instantiations (k and m known) fit 128 registers = four workgroups per CU; the run-time
+// shapes of N = 33 .. 64 need more live index arithmetic and get 256 = two workgroups per CU instead of scratch memory)
+__global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? (MST > 0 ? SLK_WGS : 2) : ((NT >= 5 && NT <= 8) ? 2 : (NT <= 2 ? 4 : 1)))) void msckf_step_kernel(KArgs a)
 {
     constexpr bool BIG = NT > 4;                           // large state (N > 64): factor + rotation store in the global workspace
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1868,6 +1871,9 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
             int *idx = ish;
             // factor-update path (see ldm_columns): the last wave scans the prefix sums of the measurement deviations
             // while the others do the S / covXZ tiles, and keeps them in registers across the gate
+            // (run-time shapes: the scan runs after the gate, right before its columns -- its 88 registers across the gate
+            // on top of their index arithmetic would not fit)
+            constexpr bool LATE_SCAN = MST == 0;
             double ldm_a[8], ldm_pf[36];
             bool ldm_on = false;
             auto ldm_scan = [&]() __attribute__((always_inline)) {
@@ -1881,7 +1887,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
             };
             measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lp, Z, DZ, Pxz, Sm, zbar, innov, &ish[42],
                                            [&](int t) { return Pin(t, t); }, colbuf, cv.pool - cv.colbuf,
-                                           WCHOL && NW == 4 && m <= 8 && a.emit == 0, ldm_scan, &ldm_on);
+                                           WCHOL && NW == 4 && m <= 8 && a.emit == 0,
+                                           [&]() __attribute__((always_inline)) { if constexpr (!LATE_SCAN) ldm_scan(); }, &ldm_on);
             SLK_STAMP(6);
             // removeOutliers (:241 -> :723-754) incl. the shifted second erase (:741-744)
             if (tid == 0) {
@@ -1940,6 +1947,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                     if (ldm_on && mmr <= 8) {
                         unsigned kept = 0;
                         for (int r = 0; r < mmr; ++r) kept |= 1u << idx[r];
+                        if constexpr (LATE_SCAN) ldm_scan();
                         const bool pd = ldm_columns(ldm_pf, ldm_a, Sm, m, kept, lane, N, Z, md);
                         st47 = pd ? 1 : 2;
                     }

@@ -43,18 +43,22 @@ __device__ __forceinline__ void qrot(const Quat &q, double vx, double vy, double
 // their temporaries and polynomial constants do not count against the callers' register budget.
 // (results by value: a local whose address goes to an out-of-line function would live in scratch memory)
 struct CosSinc { double c, s; };
-__device__ __attribute__((noinline)) CosSinc cos_sinc_sqrt_libm(double x)
+__device__ __forceinline__ CosSinc cos_sinc_sqrt_libm_body(double x)
 {
     const double sx = sqrt(x);
     return CosSinc{cos(sx), sin(sx) / sx};
 }
-__device__ __attribute__((noinline)) double so3_log_scale_libm(double n2, double w)
+__device__ __forceinline__ double so3_log_scale_libm_body(double n2, double w)
 {
     double nv = sqrt(n2);
     if (nv < 1e-11) nv = 1e-11;
     return 2.0 / nv * atan(nv / w);
 }
+__device__ __attribute__((noinline)) CosSinc cos_sinc_sqrt_libm(double x) { return cos_sinc_sqrt_libm_body(x); }
+__device__ __attribute__((noinline)) double so3_log_scale_libm(double n2, double w) { return so3_log_scale_libm_body(n2, w); }
 
+// LEAF = the libm route inlined (for callers that are out-of-line functions themselves and must stay leaves)
+template <bool LEAF = false>
 __device__ __forceinline__ void cos_sinc_sqrt(double x, double &c, double &s)
 {
     if (x < 0.25) {
@@ -78,16 +82,17 @@ __device__ __forceinline__ void cos_sinc_sqrt(double x, double &c, double &s)
         c = cc;
         s = ss;
     } else {
-        const CosSinc r = cos_sinc_sqrt_libm(x);
+        const CosSinc r = LEAF ? cos_sinc_sqrt_libm_body(x) : cos_sinc_sqrt_libm(x);
         c = r.c;
         s = r.s;
     }
 }
 
+template <bool LEAF = false>
 __device__ __forceinline__ Quat so3_exp(double vx, double vy, double vz)
 {
     double c, s;
-    cos_sinc_sqrt(0.25 * (vx * vx + vy * vy + vz * vz), c, s);
+    cos_sinc_sqrt<LEAF>(0.25 * (vx * vx + vy * vy + vz * vz), c, s);
     double m = s * 0.5;
     return Quat{m * vx, m * vy, m * vz, c};
 }
@@ -95,6 +100,7 @@ __device__ __forceinline__ Quat so3_exp(double vx, double vy, double vz)
 // MTK::SO3::log: 2 atan(|vec|/w)/|vec| * vec (|vec| clamped to 1e-11).  With u = |vec|/w the factor is
 // 2/w * atan(u)/u and atan(u)/u = sum (-u^2)^k/(2k+1): for u^2 < 1/16 (rotation below ~28 deg) the
 // series is summed directly (13 terms, < 1 ulp) -- one reciprocal instead of sqrt + 2 divisions + atan.
+template <bool LEAF = false>
 __device__ __forceinline__ void so3_log(const Quat &q, double &vx, double &vy, double &vz)
 {
     const double n2 = q.x * q.x + q.y * q.y + q.z * q.z;
@@ -121,7 +127,7 @@ __device__ __forceinline__ void so3_log(const Quat &q, double &vx, double &vy, d
         f = fma(f, y, 1.0);
         s = 2.0 * f * rw;
     } else {
-        s = so3_log_scale_libm(n2, q.w);
+        s = LEAF ? so3_log_scale_libm_body(n2, q.w) : so3_log_scale_libm(n2, q.w);
     }
     vx = s * q.x; vy = s * q.y; vz = s * q.z;
 }

@@ -208,7 +208,9 @@ __device__ inline void transform_compose(const double *t2, const double *cov2, c
 
 // ---- batch kernels: one thread per filter ------------------------------------------------------------------------
 // t2 / t1 [B][7], cov2 / cov1 [B][36] or null, additive = DeadReckon.hpp:317-323 (post = prev * delta, cov = prev + delta)
-__global__ void transform_compose_kernel(int B, const double *t2, const double *cov2, const double *t1, const double *cov1,
+// (one thread per filter with 6 x 6 Jacobian chains in registers: 64-thread workgroups at one wave per SIMD give the
+// compiler the whole register file instead of scratch memory; the op is a few hundred flops per filter, latency-bound)
+__global__ __launch_bounds__(64, 1) void transform_compose_kernel(int B, const double *t2, const double *cov2, const double *t1, const double *cov1,
                                          double *t_out, double *cov_out, int additive)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -230,7 +232,7 @@ __global__ void transform_compose_kernel(int B, const double *t2, const double *
 // DeadReckon::updatePose, RigidBodyState overload (DeadReckon.hpp:129-239).  Records (include/slk.h):
 //   prev [25] = pos quat cov_position[9] cov_orientation[9]; post [49] = that + velocity cov_velocity angular_velocity
 //   cov_angular_velocity (in/out); delta [31] = pose record + velocity angular_velocity
-__global__ void dead_reckon_pose_kernel(int B, const double *u, int u_stride, const double *velcov, int c_stride,
+__global__ __launch_bounds__(64, 1) void dead_reckon_pose_kernel(int B, const double *u, int u_stride, const double *velcov, int c_stride,
                                         const double *prev, double *post, double *delta, int use_tf)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -97,7 +97,8 @@ __device__ __forceinline__ int fast_vec_storage(int t)
 
 // ---- SO(3) exp / log with the series coefficients in an LDS table (slk_math.hpp has the same series with literal
 // coefficients: inlined a dozen times they pin 26 registers for the whole kernel).  Several arguments are evaluated in
-// lockstep so that every coefficient is fetched once.  ok = every argument inside the series' domain (else: *_slow).
+// lockstep so that every coefficient is fetched once.  ok = every argument inside the series' domain; outside it the
+// fast path hands the filter to the general body (flag ints[50], checked after the next barrier, before any global write).
 //   T[0..5]  1/14! 1/12! 1/10! 1/8! 1/6! 1/4!          cos sqrt x   (then 1/2, 1)
 //   T[6..12] 1/15! 1/13! 1/11! 1/9! 1/7! 1/5! 1/3!     sin sqrt x / sqrt x   (then 1)
 //   T[13..24] 1/25 1/23 ... 1/3                        atan u / u   (then 1)
@@ -106,15 +107,6 @@ __device__ const double fast_series_table[26] = {
     1.0 / 1307674368000.0, 1.0 / 6227020800.0, 1.0 / 39916800.0, 1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0,
     1.0 / 25.0, 1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0,
     1.0 / 3.0, 0.0};
-
-struct Dev3 { double x, y, z; };
-__device__ __attribute__((noinline)) Quat so3_exp_slow(double vx, double vy, double vz) { return so3_exp(vx, vy, vz); }
-__device__ __attribute__((noinline)) Dev3 so3_dev_slow(Quat c, double vx, double vy, double vz)
-{
-    Dev3 d;
-    so3_log(qmul(c, so3_exp(vx, vy, vz)), d.x, d.y, d.z);
-    return d;
-}
 
 // q[i] = exp(v[i]) for NV rotation vectors
 template <int NV>
@@ -517,10 +509,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
         {
             const double rv[2][3] = {{l[3], l[4], l[5]}, {-l[3], -l[4], -l[5]}};
             Quat ex[2];
-            if (!__all(so3_exp_tab<2>(T, rv, ex))) {            // a rotation column beyond the series' domain (1 rad)
-                ex[0] = so3_exp_slow(l[3], l[4], l[5]);
-                ex[1] = so3_exp_slow(-l[3], -l[4], -l[5]);
-            }
+            if (!__all(so3_exp_tab<2>(T, rv, ex))) ints[50] = 1; // a rotation column beyond the series' domain (1 rad)
             const Quat qx = Quat{x[3], x[4], x[5], x[6]};
             double lx, ly, lz;
             qrot(qconj(qmul(qx, ex[0])), fx - (x[0] + l[0]), fy - (x[1] + l[1]), fz - (x[2] + l[2]), lx, ly, lz);
@@ -542,6 +531,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
         }
     }
     __syncthreads();
+    if (ints[50]) return false;
     SLK_FSTAMP(4);
 
     // ---- phase 2: S = 1/2 sum (Z_i - mean_z)(Z_i - mean_z)^T + R (:238) on wave 1
@@ -673,8 +663,10 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             for (int Jb = 0; Jb < NT; ++Jb) {
                 double s = 0.0;
 #pragma unroll
-                for (int jj = 0; jj < 16; ++jj)
+                for (int jj = 0; jj < 16; ++jj) {
                     if (16 * Jb + jj < N) s = fma(Lrow[Jb * 256 + jj * 16], bvec[16 * Jb + jj], s);
+                    if ((jj & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // (eight columns of loads in flight at a time: registers)
+                }
                 part[Jb] = s;
             }
             double dl = part[0];
@@ -690,7 +682,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             const Quat qm = ldq(mu + so);
             const double dv[1][3] = {{delta[to], delta[to + 1], delta[to + 2]}};
             Quat ex[1];
-            if (!so3_exp_tab<1>(T, dv, ex)) ex[0] = so3_exp_slow(dv[0][0], dv[0][1], dv[0][2]);
+            if (!so3_exp_tab<1>(T, dv, ex)) ints[50] = 1;
             const Quat qr = qmul(qm, ex[0]);
             stq(ref + so, qr);
             stq(cq + 4 * lane, qmul(qconj(qr), qm));
@@ -709,7 +701,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
         SLK_WSTAMP(3, 23);
     }
     __syncthreads();
-    if (ints[48] | ints[49]) return false;                      // indefinite downdate / non-SPD S: the general body decides
+    if (ints[48] | ints[49] | ints[50]) return false;                      // indefinite downdate / non-SPD S / large rotation: the general body decides
 #ifdef SLK_EXP_A
     return true;
 #endif
@@ -727,28 +719,29 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
     // ---- manifold mean of the re-drawn sigma points (:664 -> :499-525) over (block, column) pairs: round 0 on every wave,
     // the pairs beyond 256 on wave 1, the centre points (one deviation each) on wave 2, the row sums on waves 2 / 3
     constexpr int RP = (NP + 255) / 256;                         // rounds of pairs (2 for k >= 7)
-    int aL[RP][3], aE[RP][3], aO0[RP], bb[RP];
+    int aL[RP][3], aE0[RP], bsd[RP];                            // (component 1 / 2 of E^ and the row-15 case are derived at use)
     bool val[RP];
 #pragma unroll
     for (int r = 0; r < RP; ++r) {
         const unsigned long long w = r ? pt1 : pt0;
         const unsigned lo = (unsigned)w, hi = (unsigned)(w >> 32);
         val[r] = (r ? 256 + lane : tid) < NP && (r == 0 || wave == 1);
-        const int b = (lo >> 26) & 15, sd = lo >> 30, rho = 3 * b;
-        bb[r] = b;
+        bsd[r] = lo >> 26;                                       // block | odd-part-to-str case << 4
         aL[r][0] = lo & 0x1fff; aL[r][1] = (lo >> 13) & 0x1fff; aL[r][2] = hi & 0x1fff;
-        aE[r][0] = (hi >> 13) & 0x7ff;
-        aE[r][1] = aE[r][0] + ((rho & 15) == 15 ? 49 : 1);       // (a component that crosses into the second 16 rows of E^)
-        aE[r][2] = aE[r][1] + (((rho + 1) & 15) == 15 ? 49 : 1);
-        aO0[r] = sd ? F::oStr + 16 * (int)sd - 1 : aL[r][0];
+        aE0[r] = (hi >> 13) & 0x7ff;
     }
+    auto e_off = [](int e0, int b, int cc) __attribute__((always_inline)) {     // offset of component cc in E^
+        const int rho = 3 * b;                                   // (a component that crosses into the second 16 rows: + 49)
+        const int e1 = e0 + ((rho & 15) == 15 ? 49 : 1);
+        return cc == 0 ? e0 : (cc == 1 ? e1 : e1 + (((rho + 1) & 15) == 15 ? 49 : 1));
+    };
     double dpl[RP][3], dmi[RP][3], dc[3] = {0.0, 0.0, 0.0};
     int it = 0;
     for (;;) {
 #pragma unroll
         for (int r = 0; r < RP; ++r) {
             if (r == 0 ? 64 * wave >= NP : wave != 1) continue;  // nothing for this wave in this round
-            const int b = bb[r], to = b ? 9 + 6 * b : 3;
+            const int b = bsd[r] & 15, to = b ? 9 + 6 * b : 3;
             const double l0 = smem[aL[r][0]], l1 = smem[aL[r][1]], l2 = smem[aL[r][2]];
             const double e0 = delta[to], e1 = delta[to + 1], e2 = delta[to + 2];
             const Quat cb = ldq(cq + 4 * b);
@@ -759,16 +752,12 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             ex[0] = qmul(cb, ex[0]);
             ex[1] = qmul(cb, ex[1]);
             ok = so3_log_tab<2>(T, ex, dd) && ok;
-            if (!__all(ok)) {                                    // beyond the series' domains: the libm route
-                const Dev3 a0 = so3_dev_slow(cb, rv[0][0], rv[0][1], rv[0][2]), a1 = so3_dev_slow(cb, rv[1][0], rv[1][1], rv[1][2]);
-                dd[0][0] = a0.x; dd[0][1] = a0.y; dd[0][2] = a0.z;
-                dd[1][0] = a1.x; dd[1][1] = a1.y; dd[1][2] = a1.z;
-            }
+            if (!__all(ok)) ints[50] = 1;                        // beyond the series' domains
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) { dpl[r][cc] = dd[0][cc]; dmi[r][cc] = dd[1][cc]; }
             if (val[r]) {
 #pragma unroll
-                for (int cc = 0; cc < 3; ++cc) Et[aE[r][cc]] = 0.5 * (dpl[r][cc] + dmi[r][cc]);
+                for (int cc = 0; cc < 3; ++cc) Et[e_off(aE0[r], b, cc)] = 0.5 * (dpl[r][cc] + dmi[r][cc]);
             }
         }
         if (wave == 2) {                                         // X_0 [-] ref per block
@@ -780,14 +769,12 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             bool ok = so3_exp_tab<1>(T, rv, ex);
             ex[0] = qmul(cb, ex[0]);
             ok = so3_log_tab<1>(T, ex, dd) && ok;
-            if (!__all(ok)) {
-                const Dev3 a0 = so3_dev_slow(cb, rv[0][0], rv[0][1], rv[0][2]);
-                dd[0][0] = a0.x; dd[0][1] = a0.y; dd[0][2] = a0.z;
-            }
+            if (!__all(ok)) ints[50] = 1;
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) { dc[cc] = dd[0][cc]; if (lane < NSO3) d0[3 * b + cc] = dc[cc]; }
         }
         __syncthreads();
+        if (ints[50]) return false;                              // (nothing has been written yet: the general body starts over)
         // mean_delta = sum_i (X_i [-] ref) / S (:507-509): the S - 2 (toff + 3) points beyond the block's columns equal X_0
         if (wave >= 2) {
             const int hr = wave - 2;
@@ -809,7 +796,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             const int so = lane ? 9 + 7 * lane : 3;
             const double dv[1][3] = {{md32[3 * lane], md32[3 * lane + 1], md32[3 * lane + 2]}};
             Quat ex[1];
-            if (!so3_exp_tab<1>(T, dv, ex)) ex[0] = so3_exp_slow(dv[0][0], dv[0][1], dv[0][2]);
+            if (!so3_exp_tab<1>(T, dv, ex)) ints[50] = 1;        // (a mean_delta beyond 1 rad)
             const Quat qr = qmul(ldq(ref + so), ex[0]);
             stq(ref + so, qr);
             stq(cq + 4 * lane, qmul(qconj(qr), ldq(mu + so)));
@@ -835,19 +822,19 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
 #pragma unroll
         for (int r = 0; r < RP; ++r) {
             if (r == 0 ? 64 * wave >= NP : wave != 1) continue;
-            const int b = bb[r];
+            const int b = bsd[r] & 15, sd = bsd[r] >> 4;
             const double m0 = md32[3 * b], m1 = md32[3 * b + 1], m2 = md32[3 * b + 2];
             double c0 = d0[3 * b], c1 = d0[3 * b + 1], c2 = d0[3 * b + 2];
             fix(c0, c1, c2, m0, m1, m2);
             fix(dpl[r][0], dpl[r][1], dpl[r][2], m0, m1, m2);
             fix(dmi[r][0], dmi[r][1], dmi[r][2], m0, m1, m2);
             if (val[r]) {
-                smem[aO0[r]] = 0.5 * (dpl[r][0] - dmi[r][0]);
+                smem[sd ? F::oStr + 16 * sd - 1 : aL[r][0]] = 0.5 * (dpl[r][0] - dmi[r][0]);    // (row 15's columns 16 / 17: str)
                 smem[aL[r][1]] = 0.5 * (dpl[r][1] - dmi[r][1]);
                 smem[aL[r][2]] = 0.5 * (dpl[r][2] - dmi[r][2]);
-                Et[aE[r][0]] = 0.5 * (dpl[r][0] + dmi[r][0]) - c0;
-                Et[aE[r][1]] = 0.5 * (dpl[r][1] + dmi[r][1]) - c1;
-                Et[aE[r][2]] = 0.5 * (dpl[r][2] + dmi[r][2]) - c2;
+                Et[e_off(aE0[r], b, 0)] = 0.5 * (dpl[r][0] + dmi[r][0]) - c0;
+                Et[e_off(aE0[r], b, 1)] = 0.5 * (dpl[r][1] + dmi[r][1]) - c1;
+                Et[e_off(aE0[r], b, 2)] = 0.5 * (dpl[r][2] + dmi[r][2]) - c2;
             }
         }
         if (wave == 2 && lane < NSO3) {
@@ -855,20 +842,21 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             pd[32 + 3 * lane] = dc[0]; pd[32 + 3 * lane + 1] = dc[1]; pd[32 + 3 * lane + 2] = dc[2];
         }
     }
+    __syncthreads();
+    if (ints[50]) return false;                                  // (the last move of the reference was beyond 1 rad)
     // the new mean (:664): no fallback beyond this point
     double *omean = a.mean_out ? a.mean_out + (size_t)bidx * Nq : a.mean + (size_t)bidx * Nq;
     double *oP = a.P_out ? a.P_out + (size_t)bidx * N * N : a.P + (size_t)bidx * N * N;
     if (wave == 1 && lane < N) {
-        const int s = fast_vec_storage(lane);
-        if (s >= 0) omean[s] = ref[s];
+        const int sv = fast_vec_storage(lane);
+        if (sv >= 0) omean[sv] = ref[sv];
     }
     if (wave == 0 && lane < NSO3) {
         const int so = lane ? 9 + 7 * lane : 3;
-        const Quat qr = ldq(ref + so);                           // (written by this lane above)
+        const Quat qr = ldq(ref + so);
         omean[so] = qr.x; omean[so + 1] = qr.y; omean[so + 2] = qr.z; omean[so + 3] = qr.w;
     }
     if (tid == 0) a.outliers[bidx] = nout;
-    __syncthreads();
     SLK_FSTAMP(13);
 
     // ---- P+ (:665 -> :574-589): p = sum_j e^_j + (N + 1/2) / 2 d0 by waves 2 / 3, the tile columns one per wave

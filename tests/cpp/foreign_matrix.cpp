@@ -138,6 +138,19 @@ static void ekf_run(const char *tag)
     std::snprintf(nm, sizeof nm, "%s_ekf_mean", tag); dump_mean(nm, filter.muState(), 20);
     std::snprintf(nm, sizeof nm, "%s_ekf_P", tag); dump(nm, Cov18(filter.getPk()));
     std::printf("%s_ekf_outliers 1 1 %u\n", tag, outliers);
+    // a caller-side significance test (Msckf.hpp:297-349) that rejects every block: nothing is applied (:320); one that
+    // leaves fewer rows than states: skipped and reported like the built-in gate does (the reference reads out of range)
+    {
+        MultiStateFilter f2(statek_0, Pk_0);
+        struct RejectAll { bool operator()(const double &, int) const { return false; } } none;
+        const unsigned int o2 = f2.update(z, hm, H, R, none);
+        std::snprintf(nm, sizeof nm, "%s_ekf_none_P", tag); dump(nm, Cov18(f2.getPk()));
+        std::printf("%s_ekf_none_outliers 1 1 %u\n%s_ekf_none_status 1 1 %d\n", tag, o2, tag, f2.status());
+        struct RejectSome { mutable int calls; bool operator()(const double &, int) const { return calls++ >= 4; } } some = {0};
+        const unsigned int o3 = f2.update(z, hm, H, R, some);
+        std::snprintf(nm, sizeof nm, "%s_ekf_some_P", tag); dump(nm, Cov18(f2.getPk()));
+        std::printf("%s_ekf_some_outliers 1 1 %u\n%s_ekf_some_status 1 1 %d\n", tag, o3, tag, f2.status());
+    }
 }
 
 template <class Cov12, class Vec3T, class Cov3, class Vec9T, class Cov9>

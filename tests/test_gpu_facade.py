@@ -185,6 +185,13 @@ def test_callers_own_matrix_types_through_facade():
     np.testing.assert_array_equal(r["foreign_k8_P12"], r["foreign_k8_upd_P"][:12, :12])
     assert int(r["foreign_k8_status"][0, 0]) == 0 and int(r["foreign_k2_status"][0, 0]) == 0
     assert r["foreign_usckf_PkI"].shape == (12, 12)
+    # EKF update behind a caller-side significance test: all blocks rejected -> nothing applied, 12 outliers; four blocks
+    # rejected -> 16 < 18 rows left: skipped, SLK_ST_EKF_ROWS (16) reported
+    P0 = 0.025 * np.eye(18)
+    np.testing.assert_array_equal(r["foreign_ekf_none_P"], P0)
+    assert int(r["foreign_ekf_none_outliers"][0, 0]) == 12 and int(r["foreign_ekf_none_status"][0, 0]) == 0
+    np.testing.assert_array_equal(r["foreign_ekf_some_P"], P0)
+    assert int(r["foreign_ekf_some_outliers"][0, 0]) == 4 and int(r["foreign_ekf_some_status"][0, 0]) == 16
     # k = 8 against the oracle: two predicts with the delta-pose model, one update with four features
     import scenarios as sc
     s = sc.msckf_unit_test(8)

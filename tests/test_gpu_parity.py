@@ -150,6 +150,31 @@ def test_msckf_update_with_a_wrapped_rotation_column(slk, k, m, B):
         assert rel(Pg[b], r.P) <= TOL and mean_err(lay, Mg[b], r.mean) <= TOL
 
 
+@pytest.mark.parametrize("k,var", [(8, 2.0), (8, 0.6), (5, 2.5), (4, 1.4)])
+def test_msckf_update_with_rotation_columns_beyond_one_radian(slk, k, var):
+    # rotation variances of 0.6 .. 2.5 rad^2: columns of the factor between ~0.8 and 1.6 rad -- below pi (covXZ = L A still
+    # holds) but around / beyond the 1 rad domain of the exp / log series of the exact-shape fast path (k = 4 .. 8, m = 8),
+    # which must hand such filters to the general body (libm routes) before it has written anything; mixed batch: the
+    # filters of even index keep the synthetic covariance and stay on the fast path
+    B, m = 6, 8
+    s = sc.synthetic_msckf(B, k, m=m, seed=1250 + k)
+    N = s["N"]
+    P = s["P"].copy().reshape(B, N, N)
+    for b in range(1, B, 2):
+        P[b, 3, 3] += var
+        P[b, 12 + 6 * (k - 1) + 4, 12 + 6 * (k - 1) + 4] += 0.5 * var
+    P = np.ascontiguousarray(P)
+    lay = o.layout(o.MULTI, k)
+    f = slk.Msckf(s["mean"], P)
+    f.update(s["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"], gate=0)
+    Pg, Mg = f.getPk(), f.muState()
+    for b in range(B):
+        r = o.Msckf(k, s["mean"][b], P[b])
+        st, _ = r.update(s["z"][b], o.mm_feature_proj(s["feat"][b]), s["R"], gate=False)
+        assert st == 0 and f.status()[b] == 0
+        assert rel(Pg[b], r.P) <= TOL and mean_err(lay, Mg[b], r.mean) <= TOL, b
+
+
 @pytest.mark.parametrize("k,m,B", [(2, 4, 3), (8, 8, 3), (12, 8, 3), (31, 8, 2)])
 def test_msckf_update_with_a_non_spd_innovation_covariance(slk, k, m, B):
     # R = -0.3 I makes S = cov(Z) + R indefinite: the reference inverts it with PartialPivLU all the same (Msckf.hpp:257);
