@@ -27,9 +27,11 @@
 #ifdef SLK_STAMPS
 #define SLK_FSTAMP(i) do { SLK_STAMP_NR(i); if (a.stop > 0 && a.stop == (i)) return true; } while (0)
 #define SLK_WSTAMP(w, i) do { if (tid == 64 * (w) && a.dbg) a.dbg[(size_t)bidx * 32 + (i)] = clock64(); } while (0)
+#define SLK_FBAIL(code) do { SLK_NOTE(28, code); return false; } while (0)
 #else
 #define SLK_FSTAMP(i) do { } while (0)
 #define SLK_WSTAMP(w, i) do { } while (0)
+#define SLK_FBAIL(code) return false
 #endif
 
 namespace slk {
@@ -97,8 +99,9 @@ __device__ __forceinline__ int fast_vec_storage(int t)
 
 // ---- SO(3) exp / log with the series coefficients in an LDS table (slk_math.hpp has the same series with literal
 // coefficients: inlined a dozen times they pin 26 registers for the whole kernel).  Several arguments are evaluated in
-// lockstep so that every coefficient is fetched once.  ok = every argument inside the series' domain; outside it the
-// fast path hands the filter to the general body (flag ints[50], checked after the next barrier, before any global write).
+// lockstep so that every coefficient is fetched once.  A wave whose arguments are all small takes the series directly,
+// otherwise (uniform branch) an angle-halving form that covers the whole domain the fast path can meet; exp beyond 4 rad
+// hands the filter to the general body (flag ints[50], checked after the next barrier, before any global write).
 //   T[0..5]  1/14! 1/12! 1/10! 1/8! 1/6! 1/4!          cos sqrt x   (then 1/2, 1)
 //   T[6..12] 1/15! 1/13! 1/11! 1/9! 1/7! 1/5! 1/3!     sin sqrt x / sqrt x   (then 1)
 //   T[13..24] 1/25 1/23 ... 1/3                        atan u / u   (then 1)
@@ -108,17 +111,24 @@ __device__ const double fast_series_table[26] = {
     1.0 / 25.0, 1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0,
     1.0 / 3.0, 0.0};
 
-// q[i] = exp(v[i]) for NV rotation vectors
+// q[i] = exp(v[i]) for NV rotation vectors.  Rotations below 1 rad (every lane of the wave): the series directly; otherwise
+// the series for v / 4 and two quaternion squarings, exp(v) = (exp(v / 4)^2)^2 -- up to 4 rad; ok = false beyond.
 template <int NV>
 __device__ __forceinline__ bool so3_exp_tab(const double *T, const double (&v)[NV][3], Quat (&q)[NV])
 {
     double y[NV], cc[NV], ss[NV];
-    bool ok = true;
+    bool small = true, ok = true;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const double x = 0.25 * (v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2]);
-        ok = ok && (x < 0.25);
+        small = small && (x < 0.25);
+        ok = ok && (x < 4.0);
         y[i] = -x;
+    }
+    const bool wide = !__all(small);                 // (uniform over the wave)
+    if (wide) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) y[i] *= 0.0625;   // |v / 4|^2 / 4
     }
     {
         const double c0 = T[0], s0 = T[6];
@@ -143,26 +153,69 @@ __device__ __forceinline__ bool so3_exp_tab(const double *T, const double (&v)[N
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const double m = 0.5 * ss[i];
-        q[i] = Quat{m * v[i][0], m * v[i][1], m * v[i][2], cc[i]};
+        double m = 0.5 * ss[i], w = cc[i];           // exp(v) = (m v, w);  wide: exp(v / 4) = (m / 4 v, w)
+        if (wide) {
+            m *= 0.25;
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {      // (w, m v)^2 = (2 w^2 - 1, 2 w m v) for a unit quaternion
+                const double w2 = fma(2.0 * w, w, -1.0);
+                m = 2.0 * w * m;
+                w = w2;
+            }
+        }
+        q[i] = Quat{m * v[i][0], m * v[i][1], m * v[i][2], w};
     }
     return ok;
 }
-// d[i] = log(q[i])
+// d[i] = log(q[i]) in MTK's form 2 atan(|vec| / w) / |vec| * vec (q and -q give the same result).  Rotations below ~28
+// degrees (every lane of the wave): the series of atan(u) / u directly, u = |vec| / w.  Otherwise by halved angles:
+// with w >= 0 (else take -q), t1 = tan(theta / 4) = |vec| / (1 + w) <= 1, two more halvings t <- t / (1 + sqrt(1 + t^2))
+// bring tan(theta / 16) below 0.2, theta = 16 atan(t3): every unit quaternion is inside this domain.
 template <int NV>
 __device__ __forceinline__ bool so3_log_tab(const double *T, const Quat (&q)[NV], double (&d)[NV][3])
 {
-    double y[NV], rw[NV], f[NV];
-    bool ok = true;
+    double y[NV], sc[NV], f[NV];
+    bool small = true;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const double n2 = q[i].x * q[i].x + q[i].y * q[i].y + q[i].z * q[i].z, w2 = q[i].w * q[i].w;
-        ok = ok && (q[i].w > 0.0) && (n2 * 16.0 < w2);
-        double r = __builtin_amdgcn_rcp(q[i].w);
-        r = fma(fma(-q[i].w, r, 1.0), r, r);
-        r = fma(fma(-q[i].w, r, 1.0), r, r);
-        rw[i] = r;
-        y[i] = -(n2 * r * r);
+        small = small && (q[i].w > 0.0) && (n2 * 16.0 < w2);
+        y[i] = n2;
+    }
+    const bool wide = !__all(small);                 // (uniform over the wave)
+    if (!wide) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double r = __builtin_amdgcn_rcp(q[i].w);
+            r = fma(fma(-q[i].w, r, 1.0), r, r);
+            r = fma(fma(-q[i].w, r, 1.0), r, r);
+            sc[i] = 2.0 * r;                         // log(q) = 2 / w * [atan(u) / u] * vec
+            y[i] = -(y[i] * r * r);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const double n2 = y[i], aw = fabs(q[i].w);
+            double r = __builtin_amdgcn_rcp(1.0 + aw);
+            r = fma(fma(-(1.0 + aw), r, 1.0), r, r);
+            r = fma(fma(-(1.0 + aw), r, 1.0), r, r);
+            double k = r, t2 = n2 * r * r;           // tan(theta / 4) = k |vec|, its square
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {      // t <- t / (1 + sqrt(1 + t^2))
+                const double a1 = 1.0 + t2;
+                double rs = __builtin_amdgcn_rsq(a1);
+                rs = rs * fma(-0.5 * a1 * rs, rs, 1.5);
+                rs = rs * fma(-0.5 * a1 * rs, rs, 1.5);
+                const double den = fma(a1, rs, 1.0);  // 1 + sqrt(1 + t^2)
+                double rd = __builtin_amdgcn_rcp(den);
+                rd = fma(fma(-den, rd, 1.0), rd, rd);
+                rd = fma(fma(-den, rd, 1.0), rd, rd);
+                k *= rd;
+                t2 *= rd * rd;
+            }
+            sc[i] = (q[i].w < 0.0) ? -16.0 * k : 16.0 * k;   // theta / |vec| = 16 atan(t3) / |vec| = 16 k [atan(t3) / t3]
+            y[i] = -t2;
+        }
     }
     {
         const double a0 = T[13];
@@ -178,10 +231,10 @@ __device__ __forceinline__ bool so3_log_tab(const double *T, const Quat (&q)[NV]
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         f[i] = fma(f[i], y[i], 1.0);
-        const double sc = 2.0 * f[i] * rw[i];
-        d[i][0] = sc * q[i].x; d[i][1] = sc * q[i].y; d[i][2] = sc * q[i].z;
+        const double sv = sc[i] * f[i];
+        d[i][0] = sv * q[i].x; d[i][1] = sv * q[i].y; d[i][2] = sv * q[i].z;
     }
-    return ok;
+    return true;
 }
 
 // exclusive prefix sums over the lanes (columns) of the entries E0 .. E0 + CNT - 1 of the packed lower triangle of a a^T
@@ -485,7 +538,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             if ((u >> 2) < NT && It >= (u >> 2) && It < NT) Lt[lbase + (u >> 2) * 256 + (u & 3) * 64] = in ? v[u] : 0.0;
         }
     }
-    if (__syncthreads_or(bad)) return false;
+    if (__syncthreads_or(bad)) SLK_FBAIL(2);
     SLK_FSTAMP(3);
 
     // ---- phase 1: Z = h(X) (Msckf.hpp:231-232), one wave per feature, lane j = the sigma pair of column j
@@ -531,7 +584,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
         }
     }
     __syncthreads();
-    if (ints[50]) return false;
+    if (ints[50]) SLK_FBAIL(3);
     SLK_FSTAMP(4);
 
     // ---- phase 2: S = 1/2 sum (Z_i - mean_z)(Z_i - mean_z)^T + R (:238) on wave 1
@@ -599,7 +652,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             kept = (unsigned)ix[8]; nout = (unsigned)ix[9];
         }
     }
-    if (kept == 0u) return false;                               // every block rejected (:250): status by the general body
+    if (kept == 0u) SLK_FBAIL(4);                               // every block rejected (:250): status by the general body
     SLK_FSTAMP(7);
 
     // ---- gain side.  wave 3: columns of the factor update.  wave 0: x = S^-1 nu over the surviving rows (rejected rows
@@ -701,7 +754,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
         SLK_WSTAMP(3, 23);
     }
     __syncthreads();
-    if (ints[48] | ints[49] | ints[50]) return false;                      // indefinite downdate / non-SPD S / large rotation: the general body decides
+    if (ints[48] | ints[49] | ints[50]) SLK_FBAIL(5);                      // indefinite downdate / non-SPD S / large rotation: the general body decides
 #ifdef SLK_EXP_A
     return true;
 #endif
@@ -774,7 +827,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             for (int cc = 0; cc < 3; ++cc) { dc[cc] = dd[0][cc]; if (lane < NSO3) d0[3 * b + cc] = dc[cc]; }
         }
         __syncthreads();
-        if (ints[50]) return false;                              // (nothing has been written yet: the general body starts over)
+        if (ints[50]) SLK_FBAIL(6);                              // (nothing has been written yet: the general body starts over)
         // mean_delta = sum_i (X_i [-] ref) / S (:507-509): the S - 2 (toff + 3) points beyond the block's columns equal X_0
         if (wave >= 2) {
             const int hr = wave - 2;
@@ -802,7 +855,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             stq(cq + 4 * lane, qmul(qconj(qr), ldq(mu + so)));
         }
         if (!(norm > 1e-6)) break;                               // :511
-        if (++it >= 64) return false;                            // (nothing has been written yet: the general body starts over)
+        if (++it >= 64) SLK_FBAIL(7);                            // (nothing has been written yet: the general body starts over)
         __syncthreads();
     }
     SLK_FSTAMP(12);
@@ -843,7 +896,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
         }
     }
     __syncthreads();
-    if (ints[50]) return false;                                  // (the last move of the reference was beyond 1 rad)
+    if (ints[50]) SLK_FBAIL(8);                                  // (the last move of the reference was beyond 1 rad)
     // the new mean (:664): no fallback beyond this point
     double *omean = a.mean_out ? a.mean_out + (size_t)bidx * Nq : a.mean + (size_t)bidx * Nq;
     double *oP = a.P_out ? a.P_out + (size_t)bidx * N * N : a.P + (size_t)bidx * N * N;
