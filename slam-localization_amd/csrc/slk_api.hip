@@ -363,7 +363,7 @@ static int launch_msckf(slk_filter *f, const KArgs &a0)
     case 9: case 10: return launch_msckf_inst<10, 512>(f, a);
     case 11: case 12: case 13:
         // BASELINE config 5 (N = 198): exact shape
-        if (a.lay.k == 31 && a.m == 8 && a.do_update && a.emit == 0 && a.rebuild_prec == 0) return launch_msckf_inst<13, 512, 31, 8>(f, a);
+        if (a.lay.k == 31 && a.m == 8 && a.do_update && a.emit == 0) return launch_msckf_inst<13, 512, 31, 8>(f, a);   // (any rebuild precision)
         return launch_msckf_inst<13, 512>(f, a);
     default: g_err = "state dimension above 208 is not supported by this build"; return SLK_E_UNSUPPORTED;
     }

@@ -1691,6 +1691,43 @@ struct MfmaTiles32 {
             MfmaTiles32<NT, NW, T + 1>::run_bf16(frag, acc, wave, pass);
         }
     }
+    // accumulator tiles -> LDS (doubles), tile T at T * 272, element (row, col) at col * 17 + row
+    __device__ __forceinline__ static void to_lds(double *dst, const f4 (&acc)[TPW], int wave, int lane)
+    {
+        if constexpr (T < TileMap<NT>::NTILES) {
+            if ((T % NW) == wave) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[T * 272 + (lane & 15) * 17 + 4 * (lane >> 4) + r] = (double)acc[T / NW][r];
+            }
+            MfmaTiles32<NT, NW, T + 1>::to_lds(dst, acc, wave, lane);
+        }
+    }
+    // store (scale 1) plus the matrix EEt in the index space of the rotation rows (see MfmaTiles::store_plus_rot)
+    __device__ __forceinline__ static void store_plus_rot(double *gP, int N, const f4 (&acc)[TPW], int wave, int lane, const double *EEt)
+    {
+        if constexpr (T < TileMap<NT>::NTILES) {
+            if ((T % NW) == wave) {
+                constexpr int I = TileMap<NT>::row(T), J = TileMap<NT>::col(T);
+                const int c = 16 * J + (lane & 15), rc = MfmaTiles<NT, NW, 0>::rho_of(c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = 16 * I + 4 * (lane >> 4) + r;
+                    if (rr < N && c < N) {
+                        const int r1 = MfmaTiles<NT, NW, 0>::rho_of(rr);
+                        double v = (double)acc[T / NW][r];
+                        if (r1 >= 0 && rc >= 0) {
+                            const int hi = r1 > rc ? r1 : rc, lo = r1 > rc ? rc : r1;
+                            const int ti = hi >> 4, tj = lo >> 4;
+                            v += EEt[(ti * (ti + 1) / 2 + tj) * 272 + (lo & 15) * 17 + (hi & 15)];
+                        }
+                        gP[c + (size_t)rr * N] = v;
+                        if (I != J) gP[rr + (size_t)c * N] = v;
+                    }
+                }
+            }
+            MfmaTiles32<NT, NW, T + 1>::store_plus_rot(gP, N, acc, wave, lane, EEt);
+        }
+    }
     __device__ __forceinline__ static void store(double *gP, int N, const f4 (&acc)[TPW], int wave, int lane, int pass)
     {
         if constexpr (T < TileMap<NT>::NTILES) {
@@ -1744,9 +1781,9 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
     Lay L = a.lay;
     L.kind = SLK_MSCKF;                                    // this kernel is the Msckf step: fold the layout branches
     if constexpr (KST >= 0) { L.k = KST; L.N = 12 + 6 * KST; L.Nq = 13 + 7 * KST; L.nso3 = 1 + KST; }
-    if constexpr (MST > 0) { a.m = MST; a.rebuild_prec = 0; a.emit = 0; a.do_update = 1; }     // guaranteed by the launcher
+    if constexpr (MST > 0) { a.m = MST; a.emit = 0; a.do_update = 1; if (NT <= 4) a.rebuild_prec = 0; }     // guaranteed by the launcher (large states: any rebuild precision)
     const int N = L.N, Nq = L.Nq, m = a.m, nso3 = L.nso3;
-    const Carve cv = carve_step(L, m, NT, BIG, (KST >= 0 && MST > 0) ? 0 : a.rebuild_prec);
+    const Carve cv = carve_step(L, m, NT, BIG, (KST >= 0 && MST > 0 && !BIG) ? 0 : a.rebuild_prec);
     const int S = cv.S, LDD = cv.LDD;
     double *Lp = BIG ? a.wsL + (size_t)bidx * pk_size(N) : smem + cv.Lp;
     double *mu = smem + cv.mu, *ref = smem + cv.ref;
@@ -2268,7 +2305,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
             if (!oe_rebuild && it < 10000) {
                 // the same correction for the shapes without the N <= 64 odd / even rebuild, in place (formula: see below);
                 // large states: their odd / even rebuild wants each pair as (d+ - d-) / 2, (d+ + d-) / 2 -- same pass
-                const bool pairs = BIG && a.rebuild_prec == 0;
+                const bool pairs = BIG && TilePlan<NT, NW>::PASSES == 1;      // (every rebuild precision takes the odd / even form there)
                 auto fix = [&](double &x, double &y, double &z, double m0, double m1, double m2) {
                     const double cx = y * m2 - z * m1, cy = z * m0 - x * m2, cz = x * m1 - y * m0;      // d x m
                     const double ax = y * cz - z * cy, ay = z * cx - x * cz, az = x * cy - y * cx;      // d x (d x m)
@@ -2296,7 +2333,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 }
                 __syncthreads();
             }
-            const bool big_oe = BIG && a.rebuild_prec == 0 && it < 10000;
+            const bool big_oe = BIG && it < 10000;
             if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
             SLK_STAMP(12);
             SLK_NOTE(20, it + 1);
@@ -2749,6 +2786,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                             }
                         }
                     };
+                    double *EEt = pool;             // E E^T (+ 1/2 d_0 d_0^T) meets the O O^T tiles in LDS once the panels are dead
+                    if (a.rebuild_prec == 0) {
                     d4 acc[TPW], accE[TPWE];
 #pragma unroll
                     for (int q = 0; q < TPW; ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
@@ -2777,12 +2816,93 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                         __syncthreads();
                     }
                     SLK_STAMP(14);
-                    // E E^T (+ 1/2 d_0 d_0^T) meets the O O^T tiles in LDS: the panels are dead, the E tiles go to the pool
-                    // (lower triangle of tiles, 16 x 17 each) and every stored element picks up its own
-                    double *EEt = pool;
+                    // (lower triangle of tiles, 16 x 17 each; every stored element picks up its own)
                     MfmaTiles<NTE, NW, 0>::to_lds(EEt, accE, wave, lane);
                     __syncthreads();
                     MfmaTiles<NT, NW, 0>::store_plus_rot(oP, N, acc, wave, lane, EEt);
+                    } else if (a.rebuild_prec == 1) {
+                    // ---- BASELINE config 5, fp32: the same panels, operands rounded to fp32 where they leave LDS,
+                    // v_mfma_f32_16x16x4_f32 with fp32 accumulation (half the matrix time of fp64, half the accumulator registers)
+                    f4 acc[TPW], accE[TPWE];
+#pragma unroll
+                    for (int q = 0; q < TPW; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < TPWE; ++q) accE[q] = f4{0.f, 0.f, 0.f, 0.f};
+                    double lvn[KPW][RPT], evn[KPW][2];
+                    gen_oe_load(0, lvn, evn);
+                    gen_oe_store(lvn, evn, Dp, Ep);
+                    __syncthreads();
+                    int pb = 0;
+                    for (int j0 = 0; j0 < NC; j0 += KP, pb ^= 1) {
+                        const double *Dc = Dp + pb * KP * LDD, *Ec = Ep + pb * KP * LDE;
+                        const bool more = j0 + KP < NC;
+                        if (more) gen_oe_load(j0 + KP, lvn, evn);
+#pragma unroll
+                        for (int ks = 0; ks < KP / 4; ++ks) {
+                            float frag[NT], fragE[NTE];
+#pragma unroll
+                            for (int I = 0; I < NT; ++I) frag[I] = (float)Dc[(4 * ks + (lane >> 4)) * LDD + 16 * I + (lane & 15)];
+#pragma unroll
+                            for (int I = 0; I < NTE; ++I) fragE[I] = (float)Ec[(4 * ks + (lane >> 4)) * LDE + 16 * I + (lane & 15)];
+                            MfmaTiles32<NT, NW, 0>::run(frag, acc, wave, 0);
+                            MfmaTiles32<NTE, NW, 0>::run(fragE, accE, wave, 0);
+                        }
+                        if (more) gen_oe_store(lvn, evn, Dp + (pb ^ 1) * KP * LDD, Ep + (pb ^ 1) * KP * LDE);
+                        __syncthreads();
+                    }
+                    SLK_STAMP(14);
+                    MfmaTiles32<NTE, NW, 0>::to_lds(EEt, accE, wave, lane);
+                    __syncthreads();
+                    MfmaTiles32<NT, NW, 0>::store_plus_rot(oP, N, acc, wave, lane, EEt);
+                    } else {
+                    // ---- BASELINE config 5, bf16 operands / fp32 accumulation: panels of 32 pair columns written as bf16
+                    // [row][32] (a lane's eight k-values are contiguous), v_mfma_f32_16x16x32_bf16: one matrix instruction per
+                    // tile and 32 columns instead of eight
+                    f4 acc[TPW], accE[TPWE];
+#pragma unroll
+                    for (int q = 0; q < TPW; ++q) acc[q] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < TPWE; ++q) accE[q] = f4{0.f, 0.f, 0.f, 0.f};
+                    __bf16 *Db = reinterpret_cast<__bf16 *>(Dp), *Eb = Db + TN * 32;      // [TN][32], [LDE][32]
+                    for (int j0 = 0; j0 < NC; j0 += 32) {
+                        for (int kk = wave; kk < 32; kk += NW) {
+                            const int j = j0 + kk;
+                            const int jb = pkcol(N, j < N ? j : 0);
+#pragma unroll
+                            for (int q = 0; q < RPT; ++q) {
+                                const int t = lane + 64 * q;
+                                const bool vec = rkind[q] == 1 && j < N && j <= t;
+                                const bool rot = rkind[q] == 2 && j < N && 1 + 2 * j < rcnt[q];
+                                const double *src = rot ? DR + (roffs[q] + 3 * (1 + 2 * j)) : Lp + (vec ? jb + t : 0);
+                                const double v = *src;
+                                if (t < TN) Db[t * 32 + kk] = (__bf16)(float)((vec || rot) ? v : 0.0);
+                            }
+#pragma unroll
+                            for (int qe = 0; qe < 2; ++qe) {
+                                const int rho = lane + 64 * qe;
+                                const bool in = rho < nrot && j < NC;
+                                const int b = in ? rho / 3 : 0, comp = rho - 3 * b;
+                                const int cnt = msckf_roff(b + 1) - msckf_roff(b), base = 3 * msckf_roff(b) + comp;
+                                const bool pair = j < N && 2 + 2 * j < cnt;
+                                const double v = DR[in ? base + (pair ? 3 * (2 + 2 * j) : 0) : 0];
+                                if (rho < LDE) Eb[rho * 32 + kk] = (__bf16)(float)(in ? (j == N ? v * 0.70710678118654752440 : v) : 0.0);
+                            }
+                        }
+                        __syncthreads();
+                        b8 frag[NT], fragE[NTE];
+#pragma unroll
+                        for (int I = 0; I < NT; ++I) frag[I] = *reinterpret_cast<const b8 *>(Db + (16 * I + (lane & 15)) * 32 + 8 * (lane >> 4));
+#pragma unroll
+                        for (int I = 0; I < NTE; ++I) fragE[I] = *reinterpret_cast<const b8 *>(Eb + (16 * I + (lane & 15)) * 32 + 8 * (lane >> 4));
+                        MfmaTiles32<NT, NW, 0>::run_bf16(frag, acc, wave, 0);
+                        MfmaTiles32<NTE, NW, 0>::run_bf16(fragE, accE, wave, 0);
+                        __syncthreads();
+                    }
+                    SLK_STAMP(14);
+                    MfmaTiles32<NTE, NW, 0>::to_lds(EEt, accE, wave, lane);
+                    __syncthreads();
+                    MfmaTiles32<NT, NW, 0>::store_plus_rot(oP, N, acc, wave, lane, EEt);
+                    }
                     rebuilt = true;
                 }
             }

@@ -1,6 +1,7 @@
 """Precision sweep of the covariance rebuild (BASELINE.json config 5): fp64 (parity path) vs fp32 MFMA vs
-bf16-operand / fp32-accumulate MFMA.  Same inputs, 3 fused steps; errors are measured against the fp64 GPU
-result (which itself agrees with the CPU oracle to ~1e-14) and, for a few filters, against the oracle."""
+bf16-operand / fp32-accumulate MFMA.  Same inputs; errors after 3 steps against the fp64 GPU result (which itself agrees with the CPU
+oracle to ~1e-14) and, for a few filters, against the oracle; times like bench.py (10 warm-up + 50 timed steps on one
+handle): the fp64 row is the bench row of the same shape."""
 import os
 import sys
 
@@ -11,26 +12,35 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def run(slk, s, mode, steps):
+def run(slk, s, mode, steps, warmup=10, timed=50):
+    """Errors: `steps` steps from the scenario's state on a fresh handle.  Time: like bench.py -- `warmup` untimed steps, then
+    `timed` steps on the SAME handle between two HIP events on the launch stream (inputs resident in HBM)."""
     import torch
     dev = torch.device("cuda")
-    f = slk.Msckf(s["mean"], s["P"])
-    f.set_rebuild_precision(mode)
     d = {n: torch.from_numpy(np.ascontiguousarray(s[n])).to(dev) for n in ("u", "z")}
     d["feat"] = torch.from_numpy(np.ascontiguousarray(s["feat"].reshape(s["B"], -1))).to(dev)
     d["Q"] = torch.from_numpy(np.ascontiguousarray(s["Q"].T)).to(dev)
     d["R"] = torch.from_numpy(np.ascontiguousarray(s["R"].T)).to(dev)
-    w = slk.Msckf(s["mean"], s["P"])          # untimed warm-up on a throw-away copy (module load, clocks)
-    w.set_rebuild_precision(mode)
-    w.step(slk.PM_DELTA_POSE, d["u"], d["Q"], d["z"], slk.MM_FEATURE_PROJ, d["feat"], d["R"])
-    w.sync()
-    f.sync()
-    f.timer_start()
+
+    def step(h):
+        h.step(slk.PM_DELTA_POSE, d["u"], d["Q"], d["z"], slk.MM_FEATURE_PROJ, d["feat"], d["R"])
+    f = slk.Msckf(s["mean"], s["P"])
+    f.set_rebuild_precision(mode)
     for _ in range(steps):
-        f.step(slk.PM_DELTA_POSE, d["u"], d["Q"], d["z"], slk.MM_FEATURE_PROJ, d["feat"], d["R"])
-    ms = f.timer_stop() / steps
+        step(f)
+    f.sync()
     st = f.status()
-    return f.getPk(), f.muState(), ms, int(np.count_nonzero(st & ~slk.ST_ALL_REJECTED))
+    P, M = f.getPk(), f.muState()
+    t = slk.Msckf(s["mean"], s["P"])
+    t.set_rebuild_precision(mode)
+    for _ in range(warmup):
+        step(t)
+    t.sync()
+    t.timer_start()
+    for _ in range(timed):
+        step(t)
+    ms = t.timer_stop() / timed
+    return P, M, ms, int(np.count_nonzero(st & ~slk.ST_ALL_REJECTED))
 
 
 def main():
