@@ -3014,7 +3014,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
 #define SLK_CHOL1_WAVES 3
 #endif
 template <int NT, int KST = -1>
-__global__ __launch_bounds__(64, SLK_CHOL1_WAVES) void msckf_chol_kernel(KArgs a)
+// (N <= 48: six tiles in registers -- four waves per SIMD, sixteen filters per CU: 4096 filters are one round)
+__global__ __launch_bounds__(64, (NT <= 3 ? 4 : SLK_CHOL1_WAVES)) void msckf_chol_kernel(KArgs a)
 {
     __shared__ __attribute__((aligned(16))) double colbuf[CholM<NT>::COLBUF];
     const int bidx = blockIdx.x, lane = threadIdx.x;

@@ -321,12 +321,17 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
 // 12-DOF prediction of state k+i (predict_phase), Fk = Pxy^T Pk_i^-1 (:154), then the cross blocks: rows of state k+i
 // against everything else Fk * block (:200-208, :221-232), columns against statek / statek_l block * Fk^T (:190-198),
 // feature rows as transposes (:227, :235).  All old values are staged in LDS before the first write.
-__global__ __launch_bounds__(64, 2) void usckf_predict_kernel(KArgs a)
+#ifndef SLK_UPRED_WAVES
+#define SLK_UPRED_WAVES 2
+#endif
+__global__ __launch_bounds__(64, SLK_UPRED_WAVES) void usckf_predict_kernel(KArgs a)
 {
-    __shared__ __attribute__((aligned(16))) double sm[16 + 4 * 160 + 736 + 288];
+    // (11 KB: the old columns CB take the place of the 12 x 12 factor and of Pxy, both dead once Fk stands -- fourteen
+    // filters per CU instead of eleven)
+    __shared__ __attribute__((aligned(16))) double sm[16 + 4 * 160 + 736];
     const int bidx = blockIdx.x, tid = threadIdx.x;
     const int N = a.lay.N, Nq = a.lay.Nq;
-    double *mu = sm, *Lblk = sm + 16, *Pn = Lblk + 160, *Pxy = Pn + 160, *Fk = Pxy + 160, *scr = Fk + 160, *CB = scr + 736;
+    double *mu = sm, *Pn = sm + 16, *Fk = Pn + 160, *Lblk = Fk + 160, *Pxy = Lblk + 160, *scr = Pxy + 160, *CB = Lblk;
     double *gmean = a.mean + (size_t)bidx * Nq;
     double *gP = a.P + (size_t)bidx * N * N;
     if (tid < 13) mu[tid] = gmean[26 + tid];
