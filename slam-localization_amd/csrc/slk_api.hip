@@ -324,6 +324,21 @@ static int launch_msckf_n48(slk_filter *f, const KArgs &a)                      
 }
 #endif
 
+// Windows beyond the LDS-resident kernels (N > 208; the reference's MultiState is unbounded, State.hpp:342, :373-376): the
+// plain global-workspace kernel of slk_general.hpp -- slow, but every legal call works.
+static int launch_msckf_general(slk_filter *f, const KArgs &a0)
+{
+    KArgs a = a0;
+    if (a.do_update && a.m > MAXM) { g_err = "more than 32 measurement rows per update are not supported"; return SLK_E_UNSUPPORTED; }
+    const GenWs w = general_ws(a.lay.N, a.lay.Nq, a.lay.nso3, a.m > 0 ? a.m : 1);
+    int rc = stage_reserve(f, f->ws_L, (size_t)a.B * w.total);
+    if (rc) return rc;
+    a.wsL = f->ws_L.p;
+    hipLaunchKernelGGL(msckf_update_general_kernel, dim3(a.B), dim3(256), 0, f->stream, a);
+    HIPCHECK(hipGetLastError());
+    return SLK_OK;
+}
+
 static int launch_msckf(slk_filter *f, const KArgs &a0)
 {
     KArgs a = a0;
@@ -365,7 +380,7 @@ static int launch_msckf(slk_filter *f, const KArgs &a0)
         // BASELINE config 5 (N = 198): exact shape
         if (a.lay.k == 31 && a.m == 8 && a.do_update && a.emit == 0) return launch_msckf_inst<13, 512, 31, 8>(f, a);   // (any rebuild precision)
         return launch_msckf_inst<13, 512>(f, a);
-    default: g_err = "state dimension above 208 is not supported by this build"; return SLK_E_UNSUPPORTED;
+    default: return launch_msckf_general(f, a);      // N > 208: any window length, everything in a global workspace
     }
 #endif
 }
@@ -1046,7 +1061,6 @@ static int msckf_window_op(slk_filter *f, int op, int idx)
     if (!f || f->lay.kind != SLK_MSCKF) return SLK_E_INVALID;
     const int k_old = f->lay.k, k_new = op == 1 ? k_old + 1 : k_old - 1;
     if (op == 2 && (idx < 0 || idx >= k_old)) return SLK_E_INVALID;
-    if (12 + 6 * k_new > 208) { g_err = "state dimension above 208 is not supported by this build"; return SLK_E_UNSUPPORTED; }
     HIPCHECK(hipSetDevice(f->cfg.device));
     Lay newL = make_lay(SLK_MSCKF, k_new, 0, 0);
     size_t B = (size_t)f->B;
@@ -1068,7 +1082,6 @@ int slk_msckf_drop_clone(slk_filter *f, int index) { return msckf_window_op(f, 2
 int slk_msckf_resize(slk_filter *f, int n_clones)
 {
     if (!f || f->lay.kind != SLK_MSCKF || n_clones < 0) return SLK_E_INVALID;
-    if (12 + 6 * n_clones > 208) { g_err = "state dimension above 208 is not supported by this build"; return SLK_E_UNSUPPORTED; }
     HIPCHECK(hipSetDevice(f->cfg.device));
     Lay newL = make_lay(SLK_MSCKF, n_clones, 0, 0);
     size_t B = (size_t)f->B;

@@ -3091,3 +3091,6 @@ __global__ void selftest_mfma_kernel(const double *Amat /*16x4 row-major*/, cons
 } // namespace slk
 
 #include "slk_step_fast.hpp"
+#ifndef SLK_INST_UNIT
+#include "slk_general.hpp"
+#endif

@@ -291,10 +291,52 @@ def test_api_misuse_is_rejected(slk):
     assert lib.slk_update(f._h, slk.MM_FEATURE_PROJ, None, 0, z.ctypes.data, 3, R.ctypes.data, 0, 1, slk.HOST) == slk.E_INVALID
     assert lib.slk_update(f._h, 77, None, 0, z.ctypes.data, 2, R.ctypes.data, 0, 1, slk.HOST) == slk.E_INVALID
     assert lib.slk_predict(f._h, slk.PM_DELTA_POSE, None, 0, None, 0, slk.HOST) == slk.E_INVALID
-    big = slk.Msckf(np.tile(o.identity_state(o.layout(o.MULTI, 40)), (1, 1)), np.eye(252))
-    big.predict(slk.PM_DELTA_POSE, s["u"][0], s["Q"])          # predict touches the 12 x 12 block only: any window length
-    with pytest.raises(slk.SlkError):                          # N = 252 exceeds what the update kernels are built for (208)
-        big.update(np.zeros((1, 2)), slk.MM_FEATURE_PROJ, np.array([0.0, 0.0, 5.0, 1.0]), 0.01 * np.eye(2))
+
+
+@pytest.mark.parametrize("k,m,B", [(35, 8, 2), (40, 4, 2), (49, 8, 1)])
+def test_msckf_windows_beyond_the_lds_kernels(slk, k, m, B):
+    # N = 222 / 252 / 306: the reference's MultiState is unbounded (State.hpp:342, :373-376); these windows run the plain
+    # global-workspace kernel (csrc/slk_general.hpp) -- predict + update with the gate, a second step, then the Tier-B
+    # functor path (sigma points out, Z back) and checkSigmaPoints, all against the oracle
+    s = sc.synthetic_msckf(B, k, m=m, seed=1700 + k)
+    N = s["N"]
+    lay = o.layout(o.MULTI, k)
+    f = slk.Msckf(s["mean"], s["P"])
+    ref = [o.Msckf(k, s["mean"][b], s["P"][b].reshape(N, N)) for b in range(B)]
+    z = s["z"].copy()
+    z[0, 0] += 4.0                                             # one gross outlier block in filter 0
+    for step in range(2):
+        f.step(slk.PM_DELTA_POSE, s["u"], s["Q"], z, slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+        out = f.outliers()
+        Pg, Mg = f.getPk(), f.muState()
+        assert (f.status() == 0).all()
+        for b in range(B):
+            u = s["u"][b]
+            assert ref[b].predict(o.pm_delta_pose(u[0:3], u[3:7], u[7:10], u[10:13]), s["Q"]) == 0
+            st, no = ref[b].update(z[b], o.mm_feature_proj(s["feat"][b]), s["R"])
+            assert st == 0 and no == out[b]
+            assert rel(Pg[b], ref[b].P) <= TOL and mean_err(lay, Mg[b], ref[b].mean) <= TOL, (step, b)
+    assert out[0] >= 1
+    # opaque functor path (filter 0): the same model evaluated on the host from the emitted sigma points
+    g = slk.Msckf(f.muState()[:1], f.getPk()[:1])
+    g.update_functor(s["z"][:1], lambda x: _proj(s["feat"][0], x, k), s["R"], gate=0)
+    f.update(s["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"], gate=0)
+    assert rel(g.getPk()[0], f.getPk()[0]) <= 1e-11 and mean_err(lay, g.muState()[0], f.muState()[0]) <= 1e-11
+    cov_err, mean_err_ = f.checkSigmaPoints()
+    assert cov_err.max() <= 1e-9 and mean_err_.max() <= 1e-9
+
+
+def _proj(feat, X, k):
+    """Feature projection of one sigma point (numpy): landmark in the frame of the observing pose, normalised image point."""
+    z = []
+    for fx, fy, fz, c in feat.reshape(-1, 4):
+        c = int(c)
+        sp = 0 if c == 0 else 13 + 7 * (c - 1)
+        p, q = X[sp:sp + 3], X[sp + 3:sp + 7]
+        qc = np.array([-q[0], -q[1], -q[2], q[3]])
+        l = sc.quat_rotate(qc, np.array([fx, fy, fz]) - p)
+        z += [l[0] / l[2], l[1] / l[2]]
+    return np.array(z)
 
 
 # ------------------------------------------------------------------ full-size properties (BASELINE cfg3)
