@@ -565,10 +565,19 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             if (!__all(so3_exp_tab<2>(T, rv, ex))) ints[50] = 1; // a rotation column beyond the series' domain (1 rad)
             const Quat qx = Quat{x[3], x[4], x[5], x[6]};
             double lx, ly, lz;
+            // (x / z by one refined reciprocal and a correction step: within an ulp of the IEEE quotient, half the instructions
+            // of two divisions)
+            auto quot = [](double lx_, double ly_, double lz_, double &q0, double &q1) __attribute__((always_inline)) {
+                double r = __builtin_amdgcn_rcp(lz_);
+                r = fma(fma(-lz_, r, 1.0), r, r);
+                r = fma(fma(-lz_, r, 1.0), r, r);
+                q0 = lx_ * r; q0 = fma(fma(-lz_, q0, lx_), r, q0);
+                q1 = ly_ * r; q1 = fma(fma(-lz_, q1, ly_), r, q1);
+            };
             qrot(qconj(qmul(qx, ex[0])), fx - (x[0] + l[0]), fy - (x[1] + l[1]), fz - (x[2] + l[2]), lx, ly, lz);
-            zp0 = lx / lz; zp1 = ly / lz;
+            quot(lx, ly, lz, zp0, zp1);
             qrot(qconj(qmul(qx, ex[1])), fx - (x[0] - l[0]), fy - (x[1] - l[1]), fz - (x[2] - l[2]), lx, ly, lz);
-            zm0 = lx / lz; zm1 = ly / lz;
+            quot(lx, ly, lz, zm0, zm1);
         }
         const double Z00 = readlane_f64(zp0, 63), Z01 = readlane_f64(zp1, 63);       // lanes >= tp + 6 evaluate X_0
         const double yp0 = zp0 - Z00, yp1 = zp1 - Z01, ym0 = zm0 - Z00, ym1 = zm1 - Z01;

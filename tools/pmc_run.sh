@@ -2,6 +2,7 @@
 # PMC passes for the bench kernel (counters in their own runs, no trace domains mixed in).
 # usage: tools/pmc_run.sh <tag>   (run on the GPU box; writes gpurun_out/pmc_<tag>_*.csv summaries)
 set -e
+# BENCH_ARGS (environment): extra bench.py arguments, e.g. "--filter usckf" or "--clones 31 --batch 512"
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=${1:-x}
 export TMPDIR=/tmp
@@ -9,7 +10,7 @@ OUT=/tmp/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT gpurun_out
 run() {  # name, counters...
   name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/$name.log 2>&1 || { tail -5 $OUT/$name.log; return 1; }
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS > $OUT/$name.log 2>&1 || { tail -5 $OUT/$name.log; return 1; }
   f=$(find $OUT/$name -name '*counter_collection.csv' | head -1)
   python3 - "$f" "$name" <<'PY'
 import csv, sys, collections
@@ -17,7 +18,7 @@ f, name = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for row in csv.DictReader(open(f)):
     k = row["Kernel_Name"]
-    if "msckf_" not in k: continue
+    if "msckf_" not in k and "usckf_" not in k: continue
     acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); 
     n[(k, row["Counter_Name"])] += 1
 for k in acc:
