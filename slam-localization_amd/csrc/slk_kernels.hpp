@@ -2906,8 +2906,10 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                     rebuilt = true;
                 }
             }
+            // (large states take the odd / even form above at every precision; after a mean that did not converge -- status
+            // flagged -- they rebuild in fp64 whatever the mode)
             if (rebuilt) {
-            } else if (a.rebuild_prec == 0) {
+            } else if (a.rebuild_prec == 0 || BIG) {
             for (int pass = 0; pass < TilePlan<NT, NW>::PASSES; ++pass) {
                 d4 acc[TPW];
 #pragma unroll

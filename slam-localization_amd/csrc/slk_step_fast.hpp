@@ -50,7 +50,8 @@ template <int K> struct FastShape {
     static constexpr int oDelta = oRef + ((Nq + 7) & ~7);      // 64
     static constexpr int oMd = oDelta + 64;                    // mean_delta in rotation-row space (32)
     static constexpr int oD0 = oMd + 32;                       // centre deviations (32)
-    static constexpr int oPd = oD0 + 32;                       // p [32], corrected centre deviations [32]
+    static constexpr int oD0s = oD0 + 32;                      // (S - 2 (toff + 3)) * centre deviation (32)
+    static constexpr int oPd = oD0s + 32;                      // p [32], corrected centre deviations [32]
     static constexpr int oCq = oPd + 64;                       // ref_b^-1 mu_b (4 NSO3 -> 40)
     static constexpr int oStr = oCq + 40;                      // the two odd parts of row 15 that fall into tile (0, 1)
     static constexpr int oInts = oStr + 64;                    // 64 ints
@@ -487,7 +488,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g4 = lane >> 4;
     double *Lt = smem + F::oLt, *mu = smem + F::oMu, *ref = smem + F::oRef, *delta = smem + F::oDelta, *md32 = smem + F::oMd;
-    double *d0 = smem + F::oD0, *pd = smem + F::oPd, *cq = smem + F::oCq, *str = smem + F::oStr, *U = smem + F::oU;
+    double *d0 = smem + F::oD0, *d0s = smem + F::oD0s, *pd = smem + F::oPd, *cq = smem + F::oCq, *str = smem + F::oStr, *U = smem + F::oU;
     int *ints = reinterpret_cast<int *>(smem + F::oInts);          // [0..39] gate lists of the waves, [48] [49] flags
     double *T = smem + F::oTab;
     double *Yp = U + F::uYp, *Wb = U + F::uW, *dZi = U + F::uDZ, *Sm = U + F::uSm, *mdiag = U + F::uMdiag, *bvec = U + F::uB;
@@ -833,7 +834,13 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             ok = so3_log_tab<1>(T, ex, dd) && ok;
             if (!__all(ok)) ints[50] = 1;
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc) { dc[cc] = dd[0][cc]; if (lane < NSO3) d0[3 * b + cc] = dc[cc]; }
+            for (int cc = 0; cc < 3; ++cc) {
+                dc[cc] = dd[0][cc];
+                if (lane < NSO3) {                               // (the points beyond the block's columns: weight S - 2 (toff + 3))
+                    d0[3 * b + cc] = dc[cc];
+                    d0s[3 * b + cc] = (double)(S - 2 * (b ? 12 + 6 * b : 6)) * dc[cc];
+                }
+            }
         }
         __syncthreads();
         if (ints[50]) SLK_FBAIL(6);                              // (nothing has been written yet: the general body starts over)
@@ -845,11 +852,8 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             for (int ks = 0; ks < NKS; ++ks) s += Et[(ks * 2 + hr) * 64 + lane];
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
-            const int rho = 16 * hr + c16;
-            if (g4 == 0 && rho < NROT) {
-                const int b = rho / 3, np = b ? 12 + 6 * b : 6;
-                md32[rho] = (2.0 * s + (double)(S - 2 * np) * d0[rho]) / (double)S;
-            }
+            const int rho = 16 * hr + lane;                      // (lanes 0 .. 15 hold the sums of the rows 16 hr ..)
+            if (lane < 16 && rho < NROT) md32[rho] = (2.0 * s + d0s[rho]) * (1.0 / (double)S);
         }
         __syncthreads();
         const double mdl = (lane < NROT) ? md32[lane] : 0.0;
@@ -929,8 +933,8 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
         for (int ks = 0; ks < NKS; ++ks) s += Et[(ks * 2 + hr) * 64 + lane];
         s += __shfl_xor(s, 16, 64);
         s += __shfl_xor(s, 32, 64);
-        const int rho = 16 * hr + c16;
-        if (g4 == 0 && rho < NROT) pd[rho] = s + (0.5 * ((double)N + 0.5)) * pd[32 + rho];
+        const int rho = 16 * hr + lane;
+        if (lane < 16 && rho < NROT) pd[rho] = s + (0.5 * ((double)N + 0.5)) * pd[32 + rho];
     }
     d4 acc[NT];
 #pragma unroll
