@@ -57,11 +57,14 @@ template <int K> struct FastShape {
     static constexpr int oInts = oStr + 64;                    // 64 ints
     static constexpr int oTab = oInts + 32;                    // series coefficients (26)
     static constexpr int oU = oTab + 32;                       // union region
-    // union, phases 1 - 5: Yp [64][16] (later W [512]), dZ interleaved [512], Sm, mdiag, b, innov, dz0, tmpS
-    static constexpr int uYp = 0, uW = 0, uDZ = 1024, uSm = 1536, uMdiag = 1600, uB = 1664, uInnov = 1728, uDz0 = 1736, uTmp = 1744;
-    static constexpr int USZ = (NKS * 128 > 1872) ? NKS * 128 : 1872;   // phases 6 - 7: E^ [NKS][2][64]
+    // union, phases 1 - 5: Yp [64][17] (rows [y+ ; y-] of a column, one double of padding: the lanes of a wave write
+    // different banks; later W [512] and the parked prefix sums), dZ interleaved [512], Sm, mdiag, b, innov, dz0, tmpS
+    static constexpr int uYp = 0, uW = 0, uDZ = 1088, uSm = 1600, uMdiag = 1664, uB = 1728, uInnov = 1792, uDz0 = 1800, uTmp = 1808;
+    static constexpr int USZ = (NKS * 128 > 1936) ? NKS * 128 : 1936;   // phases 6 - 7: E^ [NKS][2][64]
     static constexpr int total = oU + USZ;
 };
+
+static_assert(FastShape<8>::total * 8 * 4 <= 160 * 1024 && FastShape<7>::total * 8 * 4 <= 160 * 1024, "four workgroups per CU");
 
 __host__ __device__ inline int fast_step_lds_doubles(int k)
 {
@@ -582,8 +585,8 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
         }
         const double Z00 = readlane_f64(zp0, 63), Z01 = readlane_f64(zp1, 63);       // lanes >= tp + 6 evaluate X_0
         const double yp0 = zp0 - Z00, yp1 = zp1 - Z01, ym0 = zm0 - Z00, ym1 = zm1 - Z01;
-        Yp[j * 16 + 2 * f] = yp0; Yp[j * 16 + 2 * f + 1] = yp1;
-        Yp[j * 16 + 8 + 2 * f] = ym0; Yp[j * 16 + 8 + 2 * f + 1] = ym1;
+        Yp[j * 17 + 2 * f] = yp0; Yp[j * 17 + 2 * f + 1] = yp1;
+        Yp[j * 17 + 8 + 2 * f] = ym0; Yp[j * 17 + 8 + 2 * f + 1] = ym1;
         dZi[f * 128 + 2 * j] = yp0 - ym0; dZi[f * 128 + 2 * j + 1] = yp1 - ym1;
         const double s0 = wave_sum_f64(yp0 + ym0), s1 = wave_sum_f64(yp1 + ym1);
         if (lane == 0) {                                        // mean_z (:234) about Z_0, innovation (:236)
@@ -603,7 +606,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
         d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            const double fr = Yp[ks * 64 + lane];               // rows [y+ ; y-] of column 4 ks + g
+            const double fr = Yp[ks * 68 + g4 * 17 + c16];      // rows [y+ ; y-] of column 4 ks + g
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr, fr, acc, 0, 0, 0);
         }
         if (c16 < 8) { tmpS[g4 + 8 * c16] = acc[0]; tmpS[g4 + 4 + 8 * c16] = acc[1]; }
