@@ -9,7 +9,7 @@ SRC = os.path.join(HERE, "csrc", "slk_api.hip")
 # explicit instantiations of the largest step kernels
 UNITS = [os.path.join(HERE, "csrc", f) for f in ("slk_api.hip", "slk_inst_big.hip", "slk_inst_mid.hip")]
 DEPS = [os.path.join(HERE, "csrc", f) for f in ("slk_api.hip", "slk_inst_big.hip", "slk_inst_mid.hip", "slk_kernels.hpp", "slk_usckf.hpp",
-                                                "slk_math.hpp", "slk_step_fast.hpp", "slk_ekf.hpp", "slk_ekf_tiles.hpp", "slk_pose.hpp")]
+                                                "slk_math.hpp", "slk_step_fast.hpp", "slk_usckf_fast.hpp", "slk_general.hpp", "slk_ekf.hpp", "slk_ekf_tiles.hpp", "slk_pose.hpp")]
 DEPS.append(os.path.join(os.path.dirname(HERE), "include", "slk.h"))
 OUT = os.path.join(HERE, "libslk_hip.so")
 

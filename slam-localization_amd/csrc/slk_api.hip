@@ -429,12 +429,14 @@ static int launch_usckf_split(slk_filter *f, const KArgs &a0)
 #define SLK_USCKF_UPD_THREADS 128   // two waves per filter: twice the filters in flight, fewer barrier waits (A/B: 256 -> 188 us, 128 -> 165 us, 64 -> 172 us at B = 4096)
 #endif
     auto kern = usckf_kernel<NT, SLK_USCKF_UPD_THREADS, true>;
-    if constexpr (NT == 3) {                    // the unit-test shape: exact instantiation
-        if (a.lay.nfk == 3 && a.lay.nfkl == 9 && a.m == 3) kern = usckf_kernel<3, SLK_USCKF_UPD_THREADS, true, true>;
+    size_t lds_fast = 0;
+    if constexpr (NT == 3) {                    // the unit-test shape: exact instantiation (with its fast path's own LDS carve)
+        if (a.lay.nfk == 3 && a.lay.nfkl == 9 && a.m == 3) { kern = usckf_kernel<3, SLK_USCKF_UPD_THREADS, true, true>; lds_fast = (size_t)UFast::total * sizeof(double); }
     }
-    rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), f->cfg.device, lds);
+    const size_t lds_use = lds > lds_fast ? lds : lds_fast;
+    rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), f->cfg.device, lds_use);
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(a.B), dim3(SLK_USCKF_UPD_THREADS), lds, f->stream, a);
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(SLK_USCKF_UPD_THREADS), lds_use, f->stream, a);
     HIPCHECK(hipGetLastError());
     return SLK_OK;
 }
@@ -446,7 +448,7 @@ static int launch_usckf(slk_filter *f, const KArgs &a)
     (void)NT; (void)f; (void)a;
     g_err = "development build: Msckf only"; return SLK_E_UNSUPPORTED;
 #else
-    const bool split = a.emit == 0 && a.lay.N <= 60;       // (usckf_predict_kernel stages 12 x N old rows in 736 doubles)
+    const bool split = a.emit == 0 && a.lay.N <= 48;       // (usckf_predict_kernel stages 12 x N old rows and Fk in its 736 doubles of scratch)
     switch (NT) {
     case 3: return split ? launch_usckf_split<3>(f, a) : launch_usckf_inst<3>(f, a);
     case 4: return split ? launch_usckf_split<4>(f, a) : launch_usckf_inst<4>(f, a);

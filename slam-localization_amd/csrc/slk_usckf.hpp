@@ -8,6 +8,7 @@
 namespace slk {
 
 struct UCarve { int P, Lm, mu, small, colbuf, pool, total; int lda, S; };
+__device__ __forceinline__ bool usckf_update_fast(const KArgs &a, double *smem);     // slk_usckf_fast.hpp
 
 __host__ __device__ inline UCarve carve_usckf(int N, int Nq, int m, int NT, bool split = false)
 {
@@ -52,6 +53,11 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
     double *P = SPLIT ? gP : smem + cv.P, *Lm = smem + cv.Lm, *mu = smem + cv.mu, *colbuf = smem + cv.colbuf, *pool = smem + cv.pool;
     int *ish = reinterpret_cast<int *>(smem + cv.small);
     int status = 0;
+#ifndef SLK_NO_FAST_STEP
+    if constexpr (SPLIT && UEX && NTHREADS == 128) {
+        if (usckf_update_fast(a, smem)) return;                 // (slk_usckf_fast.hpp; false: before any global write)
+    }
+#endif
     if (a.do_update && a.emit != 4 && tid == 0) a.outliers[bidx] = 0u;
     if (tid == 0) ish[42] = 0;
 
@@ -322,16 +328,18 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
 // against everything else Fk * block (:200-208, :221-232), columns against statek / statek_l block * Fk^T (:190-198),
 // feature rows as transposes (:227, :235).  All old values are staged in LDS before the first write.
 #ifndef SLK_UPRED_WAVES
-#define SLK_UPRED_WAVES 2
+#define SLK_UPRED_WAVES 4
 #endif
 __global__ __launch_bounds__(64, SLK_UPRED_WAVES) void usckf_predict_kernel(KArgs a)
 {
-    // (11 KB: the old columns CB take the place of the 12 x 12 factor and of Pxy, both dead once Fk stands -- fourteen
-    // filters per CU instead of eleven)
-    __shared__ __attribute__((aligned(16))) double sm[16 + 4 * 160 + 736];
+    // 9.9 KB and 128 registers: sixteen filters per CU, 4096 filters are ONE round (round 2: 13.4 KB, 190 registers, eight
+    // filters per CU, two rounds of the same dependent chain).  Fk and the old rows RB live in the predict scratch (dead
+    // once predict_phase returns), the old columns CB in the place of the 12 x 12 factor and of Pxy (dead once Fk stands).
+    __shared__ __attribute__((aligned(16))) double sm[16 + 3 * 160 + 736];
     const int bidx = blockIdx.x, tid = threadIdx.x;
     const int N = a.lay.N, Nq = a.lay.Nq;
-    double *mu = sm, *Pn = sm + 16, *Fk = Pn + 160, *Lblk = Fk + 160, *Pxy = Lblk + 160, *scr = Pxy + 160, *CB = Lblk;
+    double *mu = sm, *Pn = sm + 16, *Lblk = Pn + 160, *Pxy = Lblk + 160, *scr = Pxy + 160, *CB = Lblk;
+    double *RB = scr, *Fk = scr + 580;              // 12 x N (N <= 48: 576) + 144 <= 736
     double *gmean = a.mean + (size_t)bidx * Nq;
     double *gP = a.P + (size_t)bidx * N * N;
     if (tid < 13) mu[tid] = gmean[26 + tid];
@@ -340,42 +348,55 @@ __global__ __launch_bounds__(64, SLK_UPRED_WAVES) void usckf_predict_kernel(KArg
                                        Lblk, mu, Pn, scr, Pxy);
     if (st < 0) return;                              // sigma points emitted
     if (!(st & SLK_ST_LLT_FAIL)) {
+        double fk[12];                               // lanes < 12: column tid of Fk^T = row tid of Fk
         if (tid < 12) {                              // Fk^T = Pk_i^-1 Pxy: forward + backward substitution per column
-            double x[12];
+            double rd[12];                           // reciprocal diagonal: twelve divisions instead of twenty-four
+#pragma unroll
+            for (int r = 0; r < 12; ++r) rd[r] = 1.0 / Lblk[pk(12, r, r)];
 #pragma unroll
             for (int r = 0; r < 12; ++r) {
                 double s = Pxy[r + 12 * tid];
 #pragma unroll
-                for (int p = 0; p < r; ++p) s -= Lblk[pk(12, r, p)] * x[p];
-                x[r] = s / Lblk[pk(12, r, r)];
+                for (int p = 0; p < r; ++p) s -= Lblk[pk(12, r, p)] * fk[p];
+                fk[r] = s * rd[r];
+                __builtin_amdgcn_sched_barrier(0);           // (one row of the factor in flight at a time: registers)
             }
 #pragma unroll
             for (int r = 11; r >= 0; --r) {
-                double s = x[r];
+                double s = fk[r];
 #pragma unroll
-                for (int p = r + 1; p < 12; ++p) s -= Lblk[pk(12, p, r)] * x[p];
-                x[r] = s / Lblk[pk(12, r, r)];
+                for (int p = r + 1; p < 12; ++p) s -= Lblk[pk(12, p, r)] * fk[p];
+                fk[r] = s * rd[r];
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int r = 0; r < 12; ++r) Fk[tid + 12 * r] = x[r];      // column tid of Fk^T = row tid of Fk
         }
-        double *RB = scr;                            // old rows 24..35 of P: 12 x N (ld 12); the predict scratch is dead
-        {   // all loads first (twelve + five per thread in flight), then the stores to LDS
-            double rv[12], cv[5];
+        __builtin_amdgcn_sched_barrier(0);
+        // the old rows 24..35 (12 x N, ld 12) and the old columns (rows < 24) to LDS before the first write, six loads in flight
+        for (int e0 = 0; e0 < 12 * N; e0 += 6 * 64) {
+            double rv[6];
 #pragma unroll
-            for (int q = 0; q < 12; ++q) { const int e = tid + 64 * q; rv[q] = (e < 12 * N) ? gP[(24 + e % 12) + (size_t)(e / 12) * N] : 0.0; }
+            for (int q = 0; q < 6; ++q) { const int e = e0 + tid + 64 * q; rv[q] = (e < 12 * N) ? gP[(24 + e % 12) + (size_t)(e / 12) * N] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { const int e = e0 + tid + 64 * q; if (e < 12 * N) RB[e] = rv[q]; }
+        }
+        {
+            double cv[5];
 #pragma unroll
             for (int q = 0; q < 5; ++q) { const int e = tid + 64 * q; cv[q] = (e < 24 * 12) ? gP[(e % 24) + (size_t)(24 + e / 24) * N] : 0.0; }
+            wave_sync();                             // (every lane has read its part of the factor and of Pxy)
 #pragma unroll
-            for (int q = 0; q < 12; ++q) { const int e = tid + 64 * q; if (e < 12 * N) RB[e] = rv[q]; }
+            for (int q = 0; q < 5; ++q) { const int e = tid + 64 * q; if (e < 24 * 12) CB[e] = cv[q]; }
+        }
+        if (tid < 12) {
 #pragma unroll
-            for (int q = 0; q < 5; ++q) { const int e = tid + 64 * q; if (e < 24 * 12) CB[e] = cv[q]; }     // old cols, rows < 24
+            for (int r = 0; r < 12; ++r) Fk[tid + 12 * r] = fk[r];
         }
         wave_sync();
         for (int e = tid; e < 12 * N; e += 64) {     // rows of state k+i against everything but itself: Fk * old rows
             const int r = e % 12, c = e / 12;
             if (c >= 24 && c < 36) continue;
             double s = 0.0;
+#pragma unroll 4
             for (int p = 0; p < 12; ++p) s += Fk[r + 12 * p] * RB[p + 12 * c];
             gP[(24 + r) + (size_t)c * N] = s;
             if (c >= 36) gP[c + (size_t)(24 + r) * N] = s;          // feature rows against state k+i: the transposes
@@ -383,6 +404,7 @@ __global__ __launch_bounds__(64, SLK_UPRED_WAVES) void usckf_predict_kernel(KArg
         for (int e = tid; e < 24 * 12; e += 64) {    // columns of state k+i against statek and statek_l: old cols * Fk^T
             const int r = e % 24, c = e / 24;
             double s = 0.0;
+#pragma unroll 4
             for (int p = 0; p < 12; ++p) s += CB[r + 24 * p] * Fk[c + 12 * p];
             gP[r + (size_t)(24 + c) * N] = s;
         }
@@ -461,3 +483,5 @@ __global__ void usckf_set_measurement_kernel(const double *mean, const double *P
 }
 
 } // namespace slk
+
+#include "slk_usckf_fast.hpp"
