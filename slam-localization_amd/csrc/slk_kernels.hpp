@@ -1498,15 +1498,21 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
     do {                                            // Msckf.hpp:478-487
         if (tid < 25) state_boxminus(Ys + tid * 13, refs, dbuf + tid * 12);
         wave_sync();
-        if (tid < 12) {
+        {
+            // mean over the 25 points: lane = part * 16 + component, four partial sums of 7 / 6 / 6 / 6 points, two shuffles
+            const int comp = tid & 15, part = tid >> 4;
             double sum = 0.0;
-            for (int i = 0; i < 25; ++i) sum += dbuf[i * 12 + tid];
-            mdel[tid] = sum / 25.0;
+            if (comp < 12)
+                for (int i = part; i < 25; i += 4) sum += dbuf[i * 12 + comp];
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const double mc = sum / 25.0;
+            if (tid < 12) mdel[tid] = mc;
+            const double tot = wave_inclusive_scan(tid < 12 ? mc * mc : 0.0);      // (lane 63 holds the sum)
+            const int lo = __builtin_amdgcn_readlane(__double2loint(tot), 63), hi = __builtin_amdgcn_readlane(__double2hiint(tot), 63);
+            norm = sqrt(__hiloint2double(hi, lo));
         }
         wave_sync();
-        double n2 = 0.0;
-        for (int t = 0; t < 12; ++t) n2 += mdel[t] * mdel[t];
-        norm = sqrt(n2);
         if (tid == 0) {
             double nr[13];
             state_boxplus(refs, mdel, nr);
@@ -1517,8 +1523,27 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
     SLK_STAMP_NR(23);
     SLK_NOTE(25, it + 1);
     if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
-    // covariance (Msckf.hpp:554-570) + Q (:162)
-    if (tid < 25) state_boxminus(Ys + tid * 13, refs, dbuf + tid * 12);
+    // covariance (Msckf.hpp:554-570) + Q (:162).  The loop leaves with |mean_delta| <= 1e-6: the deviations against the FINAL
+    // mean follow from the ones just taken -- vector rows d - m exactly, the rotation block by the first-order correction
+    // d' = d - Jl^-1(d) m of the update kernels (error O(|m|^2) <= 1e-12) -- instead of a fourth pass of logarithms.
+    if (tid < 25) {
+        double *d = dbuf + tid * 12;
+        if (it < 10000) {
+            const double m0 = mdel[3], m1 = mdel[4], m2 = mdel[5];
+            double x = d[3], y = d[4], z = d[5];
+            const double cx = y * m2 - z * m1, cy = z * m0 - x * m2, cz = x * m1 - y * m0;      // d x m
+            const double ax = y * cz - z * cy, ay = z * cx - x * cz, az = x * cy - y * cx;      // d x (d x m)
+            const double a12 = 1.0 / 12.0 + (x * x + y * y + z * z) * (1.0 / 720.0);
+            d[3] = x - m0 + 0.5 * cx - a12 * ax;
+            d[4] = y - m1 + 0.5 * cy - a12 * ay;
+            d[5] = z - m2 + 0.5 * cz - a12 * az;
+#pragma unroll
+            for (int c = 0; c < 12; ++c)
+                if (c < 3 || c >= 6) d[c] -= mdel[c];
+        } else {
+            state_boxminus(Ys + tid * 13, refs, d);
+        }
+    }
     wave_sync();
     const double *Q = a.Q + (size_t)bidx * a.q_stride;
     {   // 1/2 D D^T, D = 12 x 25, on the matrix cores: one 16x16 tile, seven k-steps of four sigma points
@@ -1995,19 +2020,20 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                     if (mmr <= 8) {
                         // up to four 2-row blocks: every lane factors the (padded) 8x8 matrix in registers -- no LDS
                         // round trips -- and the lanes t < N solve their row of K straight away (N <= 64: one wave)
-                        double gg[8][8];
+                        constexpr int MB = (MST > 0 && MST <= 8) ? MST : 8;      // rows known at compile time: no padding to 8 x 8
+                        double gg[MB][MB];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i)
+                        for (int i = 0; i < MB; ++i)
 #pragma unroll
                             for (int j = 0; j <= i; ++j) {
                                 const bool in = i < mmr && j < mmr;
                                 const double v = Sm[in ? idx[i] + m * idx[j] : 0];
                                 gg[i][j] = in ? v : (i == j ? 1.0 : 0.0);
                             }
-                        double gi[8];
+                        double gi[MB];
                         f0 = -1;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
+                        for (int j = 0; j < MB; ++j) {
                             double d = gg[j][j];
 #pragma unroll
                             for (int p = 0; p < j; ++p) d = fma(-gg[j][p], gg[j][p], d);
@@ -2017,7 +2043,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                             gg[j][j] = sq;
                             gi[j] = rs;
 #pragma unroll
-                            for (int i = j + 1; i < 8; ++i) {
+                            for (int i = j + 1; i < MB; ++i) {
                                 double v = gg[i][j];
 #pragma unroll
                                 for (int p = 0; p < j; ++p) v = fma(-gg[i][p], gg[j][p], v);
@@ -2029,9 +2055,9 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                         const bool fastw = ldm_on && f0 < 0;
                         if (f0 < 0) {
                             for (int t = lane; t < N; t += 64) {
-                                double x[8];
+                                double x[MB];
 #pragma unroll
-                                for (int c = 0; c < 8; ++c) {             // forward: Ls w = p
+                                for (int c = 0; c < MB; ++c) {             // forward: Ls w = p
                                     double sum = (c < mmr) ? Pxz[t + N * idx[c < mmr ? c : 0]] : 0.0;
 #pragma unroll
                                     for (int p = 0; p < c; ++p) sum = fma(-gg[c][p], x[p], sum);
@@ -2039,16 +2065,16 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                                 }
                                 double dsum = 0.0;
 #pragma unroll
-                                for (int c = 7; c >= 0; --c) {            // backward: Ls^T x = w
+                                for (int c = MB - 1; c >= 0; --c) {            // backward: Ls^T x = w
                                     double sum = x[c];
 #pragma unroll
-                                    for (int p = c + 1; p < 8; ++p) sum = fma(-gg[p][c], x[p], sum);
+                                    for (int p = c + 1; p < MB; ++p) sum = fma(-gg[p][c], x[p], sum);
                                     x[c] = sum * gi[c];
                                     if (!fastw && c < mmr) K[t + N * c] = x[c];
                                 }
                                 if (fastw) {                              // delta = K * innovation (:263), same order as below
 #pragma unroll
-                                    for (int c = 0; c < 8; ++c) dsum += (c < mmr) ? x[c] * innov[idx[c < mmr ? c : 0]] : 0.0;
+                                    for (int c = 0; c < MB; ++c) dsum += (c < mmr) ? x[c] * innov[idx[c < mmr ? c : 0]] : 0.0;
                                     delta[t] = dsum;
                                 }
                             }

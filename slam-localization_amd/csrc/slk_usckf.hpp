@@ -348,6 +348,18 @@ __global__ __launch_bounds__(64, SLK_UPRED_WAVES) void usckf_predict_kernel(KArg
                                        Lblk, mu, Pn, scr, Pxy);
     if (st < 0) return;                              // sigma points emitted
     if (!(st & SLK_ST_LLT_FAIL)) {
+        // the old columns of state k+i (rows < 24) leave for the registers now: their round trip runs under the Fk solve
+        double cv[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const int e = tid + 64 * q; cv[q] = (e < 24 * 12) ? gP[(e % 24) + (size_t)(24 + e / 24) * N] : 0.0; }
+        // the old rows 24..35 (12 x N, ld 12) to LDS before the first write (the predict scratch is dead), six loads in flight
+        for (int e0 = 0; e0 < 12 * N; e0 += 6 * 64) {
+            double rv[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { const int e = e0 + tid + 64 * q; rv[q] = (e < 12 * N) ? gP[(24 + e % 12) + (size_t)(e / 12) * N] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { const int e = e0 + tid + 64 * q; if (e < 12 * N) RB[e] = rv[q]; }
+        }
         double fk[12];                               // lanes < 12: column tid of Fk^T = row tid of Fk
         if (tid < 12) {                              // Fk^T = Pk_i^-1 Pxy: forward + backward substitution per column
             double rd[12];                           // reciprocal diagonal: twelve divisions instead of twenty-four
@@ -370,23 +382,9 @@ __global__ __launch_bounds__(64, SLK_UPRED_WAVES) void usckf_predict_kernel(KArg
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // the old rows 24..35 (12 x N, ld 12) and the old columns (rows < 24) to LDS before the first write, six loads in flight
-        for (int e0 = 0; e0 < 12 * N; e0 += 6 * 64) {
-            double rv[6];
+        wave_sync();                                 // (every lane has read its part of the factor and of Pxy: CB takes their place)
 #pragma unroll
-            for (int q = 0; q < 6; ++q) { const int e = e0 + tid + 64 * q; rv[q] = (e < 12 * N) ? gP[(24 + e % 12) + (size_t)(e / 12) * N] : 0.0; }
-#pragma unroll
-            for (int q = 0; q < 6; ++q) { const int e = e0 + tid + 64 * q; if (e < 12 * N) RB[e] = rv[q]; }
-        }
-        {
-            double cv[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) { const int e = tid + 64 * q; cv[q] = (e < 24 * 12) ? gP[(e % 24) + (size_t)(24 + e / 24) * N] : 0.0; }
-            wave_sync();                             // (every lane has read its part of the factor and of Pxy)
-#pragma unroll
-            for (int q = 0; q < 5; ++q) { const int e = tid + 64 * q; if (e < 24 * 12) CB[e] = cv[q]; }
-        }
+        for (int q = 0; q < 5; ++q) { const int e = tid + 64 * q; if (e < 24 * 12) CB[e] = cv[q]; }
         if (tid < 12) {
 #pragma unroll
             for (int r = 0; r < 12; ++r) Fk[tid + 12 * r] = fk[r];
