@@ -354,7 +354,10 @@ static int launch_msckf(slk_filter *f, const KArgs &a0)
         a.do_predict = 0;                       // the step kernel takes the predicted state from memory
     }
 #ifdef SLK_DEV_N60      // development builds (tools/ab.sh): only the headline instantiations, for quick A/B turnarounds
-#ifndef SLK_DEV_EKF     // (-DSLK_DEV_EKF: only the EKF tile kernel)
+#ifdef SLK_DEV_SMALL    // (-DSLK_DEV_SMALL: only BASELINE config 2's exact shapes, N = 12 / m = 3 and N = 18 / m = 2)
+    if (NT == 1 && a.lay.k == 0 && a.m == 3) return launch_msckf_inst<1, 64, 0, 3>(f, a);
+    if (NT == 2 && a.lay.k == 1 && a.m == 2) return launch_msckf_inst<2, 64, 1, 2>(f, a);
+#elif !defined(SLK_DEV_EKF)     // (-DSLK_DEV_EKF: only the EKF tile kernel)
     if (NT == 4) return launch_msckf_n60(f, a);
 #endif
     g_err = "development build: N = 49..64 only"; return SLK_E_UNSUPPORTED;

@@ -540,6 +540,64 @@ __device__ __forceinline__ int cholm_factor(d4 (&acc)[CholM<NT>::NTL], double *L
     return fail;
 }
 
+// ------------------------------------------------------------------ one-wave register Cholesky of a small matrix
+// lane = row, the row's NMAX columns in registers (n <= NMAX <= 32 rows live).  Per column the pivot comes by v_readlane
+// and only its RECIPROCAL (v_rcp_f64 + two Newton steps) sits on the dependent chain: the trailing update
+// a_ik -= (a_ij / d_j) a_kj uses the unscaled column, whose entries a_kj are broadcast (v_readlane) before the reciprocal
+// is known; the inverse square root that the stored column needs runs beside the chain.  No LDS round trip, no branch
+// on the chain: the smallest pivot is tracked and tested after the last column (what was stored after a non-positive
+// one is never used).  About eight dependent operations per column, against ~14 per column plus two LDS round
+// trips per four columns in cholm_factor<1> (12 x 12: 6.1 k -> cycles, profiles/r03_phase_cfg2_k0.log).
+__device__ __forceinline__ double readlane_f64(double x, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+
+template <int NMAX, class InitFn>
+__device__ __forceinline__ int chol_rows(double *Lp, int n, int lane, InitFn init)
+{
+    static_assert(NMAX <= 32, "chol_rows keeps a row per lane in registers");
+    double a[NMAX];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        // every lane fetches its whole row (lanes beyond n: row n - 1): what sits above the diagonal is never broadcast
+        // or stored, and neither a predicate nor an address per column has to stay alive
+        a[j] = init(min(lane, n - 1), j < n ? j : 0);
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (whatever init broadcasts: four columns' worth at a time)
+    }
+    double dmin = 1.0, dlast = 1.0;          // smallest pivot; the last one (a NaN anywhere has reached it)
+    // (the column loop is ONE basic block -- the factor is stored after it: with a predicated store per column the
+    // compiler sinks the trailing updates to the column that needs them and keeps every broadcast alive in between)
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        if (j < n) {
+            const double d = readlane_f64(a[j], j);
+            dmin = fmin(dmin, d);
+            dlast = d;
+            double y = __builtin_amdgcn_rcp(d);
+            double e = fma(-d, y, 1.0);
+            y = fma(y, e, y);
+            e = fma(-d, y, 1.0);
+            y = fma(y, e, y);
+            const double w = a[j] * y;
+#pragma unroll
+            for (int k = j + 1; k < NMAX; ++k) a[k] = fma(-w, readlane_f64(a[j], k), a[k]);
+            double sq, rs;
+            rsqrt_pivot(d, sq, rs);
+            (void)sq;
+            a[j] *= rs;                               // (lane j held the pivot itself: d * rs = sqrt(d) as rsqrt_pivot forms it)
+            __builtin_amdgcn_sched_barrier(0);       // one column's broadcasts (scalar registers) at a time
+        }
+    }
+    if (lane < n) {
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j)
+            if (j < n && lane >= j) Lp[pk(n, lane, j)] = a[j];
+    }
+    wave_sync();
+    return (dmin > 0.0 && dlast > 0.0) ? -1 : 0;      // (callers only test the sign)
+}
+
 // ------------------------------------------------------------------ the same factorisation over NT waves
 // Wave I owns tile row I (tiles (I, 0..I) in acc[0..I], holding -A like cholm_load): per step every wave of the
 // trailing part publishes its raw panel rows, redoes the 4x4 pivot block, forward-substitutes ONLY its own 16 rows,
@@ -1456,18 +1514,13 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
 // Lblk (packed, 78) receives its Cholesky factor (Usckf needs it for Fk); x13 = current State mean,
 // replaced by the new mean.  Pn (12x12, ld 12) receives the new block.  Returns 0 or status bits
 // (uniform), -1 after a sigma-point emission.  Runs in ONE wave (tid = lane < 64), no workgroup barrier.
-// scratch (doubles): Ys[25*13] dbuf[25*12] refs[16] mdel[16] colbuf[CholM<1>::COLBUF = 72]
+// scratch (doubles): Ys[25*13] dbuf[25*12] refs[16]  (callers still reserve the 88 doubles behind them)
 template <bool WANT_PXY, class PinFn>
 __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, PinFn pin, double *Lblk, double *x13,
                                              double *Pn, double *scr, double *Pxy /* 12x12 ld 12, only if WANT_PXY */)
 {
-    double *Ys = scr, *dbuf = scr + 25 * 13, *refs = dbuf + 25 * 12, *mdel = refs + 16, *cb = mdel + 16;
-    int fail;
-    {
-        d4 acc[1];
-        cholm_load<1>(acc, 12, tid, pin);
-        fail = cholm_factor<1>(acc, Lblk, 12, cb, tid);
-    }
+    double *Ys = scr, *dbuf = scr + 25 * 13, *refs = dbuf + 25 * 12;
+    const int fail = chol_rows<12>(Lblk, 12, tid, pin);
     SLK_STAMP_NR(21);
     if (fail >= 0) return SLK_ST_LLT_FAIL;
     const double *u = a.u ? a.u + (size_t)bidx * a.u_stride : nullptr;
@@ -1490,14 +1543,35 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
     }
     if (a.emit == 1) return -1;   // sigma points emitted, nothing else to do
     wave_sync();
-    if (tid < 13) refs[tid] = Ys[tid];              // reference = X[0]  (Msckf.hpp:473)
-    wave_sync();
+    // Manifold mean (Msckf.hpp:473-487).  Sigma point tid keeps its quaternion and its vector-row deviations in
+    // registers, EVERY lane keeps the reference quaternion and moves it itself (the vector rows of the reference sit in
+    // LDS, moved by the lane of their component): per pass one LDS transposition (the 25 x 12 deviations, summed by four
+    // lanes per component) instead of three round trips, one logarithm and one exponential.  The vector rows are kept as
+    // deviations, d <- d - mean(d) (= a - (ref + mean) up to rounding); the loop test is on the squared norm.
     int it = 0, status = 0;
-    double norm;
+    Quat q, rq;
+    double dv[9], dr[3], mr[3];
+    {
+        const double *yrow = Ys + (tid < 25 ? tid : 0) * 13;
+        q = ldq(yrow + 3);
+        rq = ldq(Ys + 3);                                                        // reference = X[0]  (Msckf.hpp:473)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { const int sidx = c < 3 ? c : c + 4; dv[c] = yrow[sidx] - Ys[sidx]; }
+        if (tid < 13) refs[tid] = Ys[tid];
+    }
     SLK_STAMP_NR(22);
+    double n2;
     do {                                            // Msckf.hpp:478-487
-        if (tid < 25) state_boxminus(Ys + tid * 13, refs, dbuf + tid * 12);
+        so3_boxminus(q, rq, dr[0], dr[1], dr[2]);
+        if (tid < 25) {
+            double *row = dbuf + tid * 12;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { row[c] = dv[c]; row[3 + c] = dr[c]; }
+#pragma unroll
+            for (int c = 3; c < 9; ++c) row[3 + c] = dv[c];
+        }
         wave_sync();
+        double mv[9];
         {
             // mean over the 25 points: lane = part * 16 + component, four partial sums of 7 / 6 / 6 / 6 points, two shuffles
             const int comp = tid & 15, part = tid >> 4;
@@ -1506,43 +1580,45 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
                 for (int i = part; i < 25; i += 4) sum += dbuf[i * 12 + comp];
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
-            const double mc = sum / 25.0;
-            if (tid < 12) mdel[tid] = mc;
-            const double tot = wave_inclusive_scan(tid < 12 ? mc * mc : 0.0);      // (lane 63 holds the sum)
-            const int lo = __builtin_amdgcn_readlane(__double2loint(tot), 63), hi = __builtin_amdgcn_readlane(__double2hiint(tot), 63);
-            norm = sqrt(__hiloint2double(hi, lo));
+            const double mc = sum * (1.0 / 25.0);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) mr[c] = readlane_f64(mc, 3 + c);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) mv[c] = readlane_f64(mc, c < 3 ? c : c + 3);
+            if (tid < 12 && (tid < 3 || tid >= 6)) refs[tid < 3 ? tid : tid + 1] += mc;
         }
-        wave_sync();
-        if (tid == 0) {
-            double nr[13];
-            state_boxplus(refs, mdel, nr);
-            for (int c = 0; c < 13; ++c) refs[c] = nr[c];
-        }
-        wave_sync();
-    } while (norm > 1e-6 && ++it < 10000);
+        n2 = ((mv[0] * mv[0] + mv[1] * mv[1]) + (mv[2] * mv[2] + mr[0] * mr[0]))
+           + ((mr[1] * mr[1] + mr[2] * mr[2]) + (mv[3] * mv[3] + mv[4] * mv[4]))
+           + ((mv[5] * mv[5] + mv[6] * mv[6]) + (mv[7] * mv[7] + mv[8] * mv[8]));
+        rq = qmul(rq, so3_exp(mr[0], mr[1], mr[2]));
+#pragma unroll
+        for (int c = 0; c < 9; ++c) dv[c] -= mv[c];
+        wave_sync();                                // (the next pass rewrites dbuf)
+    } while (n2 > 1e-12 && ++it < 10000);
     SLK_STAMP_NR(23);
     SLK_NOTE(25, it + 1);
     if (it >= 10000) status |= SLK_ST_MEAN_NOT_CONVERGED;
     // covariance (Msckf.hpp:554-570) + Q (:162).  The loop leaves with |mean_delta| <= 1e-6: the deviations against the FINAL
-    // mean follow from the ones just taken -- vector rows d - m exactly, the rotation block by the first-order correction
-    // d' = d - Jl^-1(d) m of the update kernels (error O(|m|^2) <= 1e-12) -- instead of a fourth pass of logarithms.
+    // mean follow from the ones just taken -- the vector rows are there already, the rotation block by the first-order
+    // correction d' = d - Jl^-1(d) m of the update kernels (error O(|m|^2) <= 1e-12) -- instead of another pass of logarithms.
     if (tid < 25) {
-        double *d = dbuf + tid * 12;
         if (it < 10000) {
-            const double m0 = mdel[3], m1 = mdel[4], m2 = mdel[5];
-            double x = d[3], y = d[4], z = d[5];
+            const double m0 = mr[0], m1 = mr[1], m2 = mr[2];
+            const double x = dr[0], y = dr[1], z = dr[2];
             const double cx = y * m2 - z * m1, cy = z * m0 - x * m2, cz = x * m1 - y * m0;      // d x m
             const double ax = y * cz - z * cy, ay = z * cx - x * cz, az = x * cy - y * cx;      // d x (d x m)
             const double a12 = 1.0 / 12.0 + (x * x + y * y + z * z) * (1.0 / 720.0);
-            d[3] = x - m0 + 0.5 * cx - a12 * ax;
-            d[4] = y - m1 + 0.5 * cy - a12 * ay;
-            d[5] = z - m2 + 0.5 * cz - a12 * az;
-#pragma unroll
-            for (int c = 0; c < 12; ++c)
-                if (c < 3 || c >= 6) d[c] -= mdel[c];
+            dr[0] = x - m0 + 0.5 * cx - a12 * ax;
+            dr[1] = y - m1 + 0.5 * cy - a12 * ay;
+            dr[2] = z - m2 + 0.5 * cz - a12 * az;
         } else {
-            state_boxminus(Ys + tid * 13, refs, d);
+            so3_boxminus(q, rq, dr[0], dr[1], dr[2]);
         }
+        double *row = dbuf + tid * 12;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { row[c] = dv[c]; row[3 + c] = dr[c]; }
+#pragma unroll
+        for (int c = 3; c < 9; ++c) row[3 + c] = dv[c];
     }
     wave_sync();
     const double *Q = a.Q + (size_t)bidx * a.q_stride;
@@ -1583,7 +1659,8 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
         }
     }
     wave_sync();
-    if (tid < 13) x13[tid] = refs[tid];
+    if (tid < 13 && (tid < 3 || tid >= 7)) x13[tid] = refs[tid];
+    if (tid == 0) stq(x13 + 3, rq);
     wave_sync();
     return status;
 }
@@ -1802,6 +1879,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
     constexpr int GD = Grid<NTHREADS>::GD;
     constexpr int SDN = (16 * NT + GD - 1) / GD;          // Cholesky register slots per dimension
     constexpr int SDM = (MAXM + GD - 1) / GD;
+    constexpr int NROWS = (NT <= 2 && KST >= 0) ? 12 + 6 * KST : 1;      // rows of the one-wave register Cholesky (exact shapes, N <= 32)
+    static_assert(NT > 2 || NTHREADS == 64, "states of N <= 32 run one wave per filter");
     const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Lay L = a.lay;
     L.kind = SLK_MSCKF;                                    // this kernel is the Msckf step: fold the layout branches
@@ -1860,7 +1939,31 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
         }
     }
     // lower-triangle element of the covariance (only the lower triangle of Pk is ever read: LLT at :412, :447)
-    auto Pin = [&](int i, int j) -> double { return (NT <= 2 && pred12 && i < 12 && j < 12) ? Pn12[i + 12 * j] : gP[i + (size_t)j * N]; };
+    // (both sources are fetched and the VALUE is selected: a select between an LDS and a global pointer turns every access
+    // into a flat load with a 64-bit address of its own, kept alive from the first factorisation to the second)
+    auto Pin = [&](int i, int j) -> double {
+        const double g = gP[i + (size_t)j * N];
+        if constexpr (NT <= 2) {
+            const double l = Pn12[min(i, 11) + 12 * min(j, 11)];
+            return (pred12 && i < 12 && j < 12) ? l : g;
+        }
+        return g;
+    };
+    // exact shapes of N <= 32: the one-wave register Cholesky of Pk - (downdate), lane = row (chol_rows hands row
+    // min(lane, N - 1) to its element function; down(j) is that row's downdate of column j).  After a predict in this
+    // launch the 12 x 12 block comes from LDS -- for N = 12 nothing is fetched from global memory at all.
+    auto chol_state = [&](auto down) -> int {
+        if (pred12)
+            return chol_rows<NROWS>(Lp, NROWS, lane, [&](int i, int j) -> double {
+                if constexpr (NROWS == 12) return Pn12[i + 12 * j] - down(j);
+                if (j < 12) {
+                    const double l = Pn12[min(i, 11) + 12 * j], g = gP[i + (size_t)j * N];
+                    return (i < 12 ? l : g) - down(j);
+                }
+                return gP[i + (size_t)j * N] - down(j);
+            });
+        return chol_rows<NROWS>(Lp, NROWS, lane, [&](int i, int j) -> double { return gP[i + (size_t)j * N] - down(j); });
+    };
 
     SLK_STAMP(2);
     if (a.do_update || a.emit >= 2) {
@@ -1879,6 +1982,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
             }
             fail = a.wsfail[bidx];
             __syncthreads();
+        } else if constexpr (NT <= 2 && KST >= 0) {
+            fail = chol_state([](int) { return 0.0; });                // (one wave per filter: no barrier)
         } else if constexpr (NT <= 4) {
             if (wave == 0) {
                 d4 acc[CholM<NT>::NTL];
@@ -2180,6 +2285,20 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                                                [&](int r, int c) { return K[r + N * c]; });
                             fail = cholw_factor<NT>(acc, Lp, N, colbuf, md, lane, wave, &ish[45]);
                         }
+                    } else if constexpr (NT <= 2 && KST >= 0 && MST > 0) {
+                        double xv[MST], kv[MST];                       // this lane's rows of covXZ (kept columns) and of K
+#pragma unroll
+                        for (int c = 0; c < MST; ++c) {
+                            const int row = min(lane, N - 1), cc = c < mmr ? c : 0;
+                            xv[c] = (c < mmr) ? Pxz[row + N * idx[cc]] : 0.0;
+                            kv[c] = (c < mmr) ? K[row + N * cc] : 0.0;
+                        }
+                        fail = chol_state([&](int j) {                 // (K(j, c) broadcast from lane j: scalar registers)
+                            double sum = 0.0;
+#pragma unroll
+                            for (int c = 0; c < MST; ++c) sum = fma(xv[c], readlane_f64(kv[c], j), sum);
+                            return sum;
+                        });
                     } else if constexpr (NT <= 4) {
                         if (wave == 0) {
                             d4 acc[CholM<NT>::NTL];

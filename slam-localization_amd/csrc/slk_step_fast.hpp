@@ -78,11 +78,6 @@ __host__ __device__ inline int fast_step_lds_doubles(int k)
     }
 }
 
-__device__ __forceinline__ double readlane_f64(double x, int l)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
-    return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double wave_sum_f64(double x) { return readlane_f64(wave_inclusive_scan(x), 63); }
 
 // rotation-row index (3 b + comp) of tangent row t, 31 (an all-zero row of E^ / p / d0) for vector rows and padding

@@ -40,12 +40,16 @@ def main():
     slk._lib = lib                       # route the host mirror through the diagnostic library
     lib.slk_debug_set_stamps.argtypes = [C.c_void_p]
     B, k, m = args.batch, args.clones, args.meas
-    s = sc.synthetic_msckf(B, k, m=m)
+    s = sc.synthetic_msckf(B, k, m=(m if m != 3 else 2))
     f = slk.Msckf(s["mean"], s["P"])
     dbg = torch.zeros((B, 32), dtype=torch.int64, device="cuda")
     lib.slk_debug_set_stamps(dbg.data_ptr())
     for _ in range(args.steps):
-        f.step(slk.PM_DELTA_POSE, s["u"], s["Q"], s["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+        if m == 3:      # bench.py's config-2 workload: position fix of pose 0
+            f.step(slk.PM_DELTA_POSE, s["u"], s["Q"], s["mean"][:, 0:3] + 0.05, slk.MM_POSE_POSITION, np.zeros(1), 0.01 * np.eye(3),
+                   gate=0)
+        else:
+            f.step(slk.PM_DELTA_POSE, s["u"], s["Q"], s["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"])
     f.sync()
     t = dbg.cpu().numpy()
     ok = t[:, 15] > 0
