@@ -540,19 +540,98 @@ __device__ __forceinline__ int cholm_factor(d4 (&acc)[CholM<NT>::NTL], double *L
     return fail;
 }
 
-// ------------------------------------------------------------------ one-wave register Cholesky of a small matrix
-// lane = row, the row's NMAX columns in registers (n <= NMAX <= 32 rows live).  Per column the pivot comes by v_readlane
-// and only its RECIPROCAL (v_rcp_f64 + two Newton steps) sits on the dependent chain: the trailing update
-// a_ik -= (a_ij / d_j) a_kj uses the unscaled column, whose entries a_kj are broadcast (v_readlane) before the reciprocal
-// is known; the inverse square root that the stored column needs runs beside the chain.  No LDS round trip, no branch
-// on the chain: the smallest pivot is tracked and tested after the last column (what was stored after a non-positive
-// one is never used).  About eight dependent operations per column, against ~14 per column plus two LDS round
-// trips per four columns in cholm_factor<1> (12 x 12: 6.1 k -> cycles, profiles/r03_phase_cfg2_k0.log).
 __device__ __forceinline__ double readlane_f64(double x, int l)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
 }
 
+// ------------------------------------------------------------------ the same blocked factorisation, panel by rows
+// cholm_factor's step has every lane redo the 4 x 4 pivot block and forward-substitute four columns for each of its
+// tile rows, then pick one of the four results: ~250 vector instructions per step, and one wave per filter runs at
+// the rate of its instruction count (msckf_chol_kernel: 3.9 k per filter, 46 us per 4096 filters).  Here the four
+// published columns are read back with lane = ROW (one value per column), the 64 x 4 panel is factored once for all
+// rows -- per column: pivot by v_readlane, v_rsq_f64 + two Newton steps, one scale, one multiply-add per remaining
+// panel column -- written to LDS again and fetched as the matrix-core fragments of the rank-4 update; the packed factor
+// is stored straight from the row layout.  A non-positive pivot is recorded; what follows it is never used.
+template <int NT, int JK, int C0>
+struct CholPSteps {
+    __device__ __forceinline__ static void run(d4 (&acc)[CholM<NT>::NTL], double *Lp, int n, double *colbuf, int lane, bool &bad)
+    {
+        if constexpr (JK < NT) {
+            constexpr int LDC = CholM<NT>::LDC;
+            constexpr int k0 = 16 * JK + C0;
+            if (k0 < n) {
+                const int c = lane & 15, g = lane >> 4;
+                const int row = (NT == 4) ? lane : min(lane, 16 * NT - 1);
+                // 1. publish the four pivot columns, raw (the accumulators hold -A)
+                if (c >= C0 && c < C0 + 4) {
+                    double *dst = colbuf + (c - C0) * LDC + g;
+#pragma unroll
+                    for (int I = JK; I < NT; ++I)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dst[16 * I + 4 * r] = acc[tile_idx(I, JK)][r];
+                }
+                wave_sync();
+                // 2. this lane's row of the panel, and the four columns
+                double l[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) l[p] = -colbuf[p * LDC + row];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const double d = readlane_f64(l[p], k0 + p);
+                    bad |= !(d > 0.0);
+                    double sq, rs;
+                    rsqrt_pivot(d, sq, rs);
+                    (void)sq;
+                    l[p] *= rs;                                   // (lane k0 + p held the pivot: d * rs = sqrt(d))
+#pragma unroll
+                    for (int q = p + 1; q < 4; ++q) l[q] = fma(-l[p], readlane_f64(l[p], k0 + q), l[q]);
+                }
+                // (rows above the diagonal of the pivot block and retired rows carry garbage: as fragments they only reach
+                // accumulator slots that are dead after this step, and the packed factor takes rows >= column only)
+                // 3. the factor panel: to LDS for the fragments, to the packed factor from the row layout
+                wave_sync();
+                if (NT == 4 || lane < 16 * NT) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) colbuf[p * LDC + lane] = l[p];
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (k0 + p < n && lane >= k0 + p && lane < n) Lp[pkcol(n, k0 + p) + lane] = l[p];
+                wave_sync();
+                double frag[NT];
+#pragma unroll
+                for (int I = JK; I < NT; ++I) frag[I] = colbuf[g * LDC + 16 * I + c];
+                wave_sync();       // the next step's publish must not overtake these reads
+                // 4. rank-4 update of the trailing tiles (the tiles the next step publishes first)
+#pragma unroll
+                for (int J = JK; J < NT; ++J)
+#pragma unroll
+                    for (int I = J; I < NT; ++I)
+                        acc[tile_idx(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[I], frag[J], acc[tile_idx(I, J)], 0, 0, 0);
+            }
+            CholPSteps<NT, (C0 == 12 ? JK + 1 : JK), (C0 + 4) & 15>::run(acc, Lp, n, colbuf, lane, bad);
+        }
+    }
+};
+
+// factor the matrix held in `acc` (see cholm_load); wave-local, returns -1 or 0 (some pivot was not positive)
+template <int NT>
+__device__ __forceinline__ int cholp_factor(d4 (&acc)[CholM<NT>::NTL], double *Lp, int n, double *colbuf, int lane)
+{
+    bool bad = false;
+    CholPSteps<NT, 0, 0>::run(acc, Lp, n, colbuf, lane, bad);
+    wave_sync();
+    return bad ? 0 : -1;
+}
+
+// ------------------------------------------------------------------ one-wave register Cholesky of a small matrix
+// lane = row, the row's NMAX columns in registers (n <= NMAX <= 32 rows live).  Per column: the pivot by v_readlane, its
+// inverse square root (v_rsq_f64 + two Newton steps), one scale, and per trailing column one broadcast (v_readlane) and
+// one multiply-add -- a single wave runs at the rate of its instruction count (an fp64 operation issues every ~10.6
+// cycles whether or not it depends on the one before: profiles/r01_mfma_valu_overlap.log), so the count is what is
+// minimised.  No LDS round trip, no branch: a non-positive pivot is recorded (what follows it is never used).
+// 12 x 12: 6.1 k -> 4.6 k cycles including the load of the matrix (profiles/r03_ab_small_state_register_cholesky.log).
 template <int NMAX, class InitFn>
 __device__ __forceinline__ int chol_rows(double *Lp, int n, int lane, InitFn init)
 {
@@ -565,27 +644,20 @@ __device__ __forceinline__ int chol_rows(double *Lp, int n, int lane, InitFn ini
         a[j] = init(min(lane, n - 1), j < n ? j : 0);
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (whatever init broadcasts: four columns' worth at a time)
     }
-    double dmin = 1.0, dlast = 1.0;          // smallest pivot; the last one (a NaN anywhere has reached it)
+    bool bad = false;
     // (the column loop is ONE basic block -- the factor is stored after it: with a predicated store per column the
     // compiler sinks the trailing updates to the column that needs them and keeps every broadcast alive in between)
 #pragma unroll
     for (int j = 0; j < NMAX; ++j) {
         if (j < n) {
             const double d = readlane_f64(a[j], j);
-            dmin = fmin(dmin, d);
-            dlast = d;
-            double y = __builtin_amdgcn_rcp(d);
-            double e = fma(-d, y, 1.0);
-            y = fma(y, e, y);
-            e = fma(-d, y, 1.0);
-            y = fma(y, e, y);
-            const double w = a[j] * y;
-#pragma unroll
-            for (int k = j + 1; k < NMAX; ++k) a[k] = fma(-w, readlane_f64(a[j], k), a[k]);
+            bad |= !(d > 0.0);
             double sq, rs;
             rsqrt_pivot(d, sq, rs);
             (void)sq;
             a[j] *= rs;                               // (lane j held the pivot itself: d * rs = sqrt(d) as rsqrt_pivot forms it)
+#pragma unroll
+            for (int k = j + 1; k < NMAX; ++k) a[k] = fma(-a[j], readlane_f64(a[j], k), a[k]);
             __builtin_amdgcn_sched_barrier(0);       // one column's broadcasts (scalar registers) at a time
         }
     }
@@ -595,7 +667,7 @@ __device__ __forceinline__ int chol_rows(double *Lp, int n, int lane, InitFn ini
             if (j < n && lane >= j) Lp[pk(n, lane, j)] = a[j];
     }
     wave_sync();
-    return (dmin > 0.0 && dlast > 0.0) ? -1 : 0;      // (callers only test the sign)
+    return bad ? 0 : -1;      // (callers only test the sign)
 }
 
 // ------------------------------------------------------------------ the same factorisation over NT waves
@@ -3170,7 +3242,11 @@ __global__ __launch_bounds__(64, (NT <= 3 ? 4 : SLK_CHOL1_WAVES)) void msckf_cho
     const double *gP = a.P + (size_t)bidx * N * N;
     d4 acc[CholM<NT>::NTL];
     cholm_load<NT>(acc, N, lane, [&](int i, int j) { return gP[i + (size_t)j * N]; });
+#ifdef SLK_CHOL_BY_TILES
     const int fail = cholm_factor<NT>(acc, a.wsL + (size_t)bidx * pk_size(N), N, colbuf, lane);
+#else
+    const int fail = cholp_factor<NT>(acc, a.wsL + (size_t)bidx * pk_size(N), N, colbuf, lane);
+#endif
     if (lane == 0) a.wsfail[bidx] = fail;
 }
 
