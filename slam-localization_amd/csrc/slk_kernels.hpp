@@ -1584,7 +1584,7 @@ __device__ __forceinline__ void measurement_moments(const KArgs &a, const Lay &L
 // Msckf.hpp:102-165 == Usckf.hpp:117-181: sigma points of the current State, process model map,
 // manifold mean, new Pk_i = cov + Q.  pin(i, j) = lower triangle of the 12x12 covariance block;
 // Lblk (packed, 78) receives its Cholesky factor (Usckf needs it for Fk); x13 = current State mean,
-// replaced by the new mean.  Pn (12x12, ld 12) receives the new block.  Returns 0 or status bits
+// replaced by the new mean.  Pn (12x12, ld 12) receives the new block, Pxy (WANT_PXY) the matrix M = L^-1 Pxy.  Returns 0 or status bits
 // (uniform), -1 after a sigma-point emission.  Runs in ONE wave (tid = lane < 64), no workgroup barrier.
 // scratch (doubles): Ys[25*13] dbuf[25*12] refs[16]  (callers still reserve the 88 doubles behind them)
 template <bool WANT_PXY, class PinFn>
@@ -1718,17 +1718,11 @@ __device__ __forceinline__ int predict_phase(const KArgs &a, int bidx, int tid, 
         }
     }
     for (int e = tid; WANT_PXY && e < 144; e += 64) {
-        int r = e % 12, c = e / 12;
-        {
-            // Pxy = 1/2 sum (XCopy_i [-] mu_old)(X_i [-] mu_new)^T, XCopy_i [-] mu_old = +-L.col(j)
-            // (Usckf.hpp:152-153, :691-712)
-            double sx = 0.0;
-            for (int i = 1; i < 25; ++i) {
-                Sig s = sig_of(i);
-                sx += s.sgn * Lz(Lblk, 12, r, s.j) * dbuf[i * 12 + c];
-            }
-            Pxy[e] = 0.5 * sx;
-        }
+        // Pxy = 1/2 sum (XCopy_i [-] mu_old)(X_i [-] mu_new)^T with XCopy_i [-] mu_old = +-L.col(j) (Usckf.hpp:152-153,
+        // :691-712), i.e. Pxy = L M with M(j, c) = 1/2 (d_{+j}(c) - d_{-j}(c)): the callers want Fk^T = Pk_i^-1 Pxy =
+        // L^-T M (:154) -- M itself is handed out (element (j, c) at j + 12 c) and the forward substitution never runs
+        const int j = e % 12, c = e / 12;
+        Pxy[e] = 0.5 * (dbuf[(2 * j + 1) * 12 + c] - dbuf[(2 * j + 2) * 12 + c]);
     }
     wave_sync();
     if (tid < 13 && (tid < 3 || tid >= 7)) x13[tid] = refs[tid];

@@ -83,17 +83,12 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
         if (a.emit == 1) return;
         status |= st;
         if (!(st & SLK_ST_LLT_FAIL)) {
-            // Fk = Pxy^T * Pk_i^-1 (:154).  Pk_i = L L^T (its Cholesky factor is in Pblk), so
-            // Fk^T = Pk_i^-1 Pxy: one forward + one backward substitution per column (Lblk = packed factor).
+            // Fk = Pxy^T * Pk_i^-1 (:154).  Pk_i = L L^T (its Cholesky factor is in Lblk) and Pxy = L M (predict_phase hands
+            // out M): Fk^T = L^-T M, one backward substitution per column.
             if (tid < 12) {
                 double x[12];
-                for (int r = 0; r < 12; ++r) {
-                    double s = Pxy[r + 12 * tid];
-                    for (int p = 0; p < r; ++p) s -= Lblk[pk(12, r, p)] * x[p];
-                    x[r] = s / Lblk[pk(12, r, r)];
-                }
                 for (int r = 11; r >= 0; --r) {
-                    double s = x[r];
+                    double s = Pxy[r + 12 * tid];
                     for (int p = r + 1; p < 12; ++p) s -= Lblk[pk(12, p, r)] * x[p];
                     x[r] = s / Lblk[pk(12, r, r)];
                 }
@@ -361,25 +356,18 @@ __global__ __launch_bounds__(64, SLK_UPRED_WAVES) void usckf_predict_kernel(KArg
             for (int q = 0; q < 6; ++q) { const int e = e0 + tid + 64 * q; if (e < 12 * N) RB[e] = rv[q]; }
         }
         double fk[12];                               // lanes < 12: column tid of Fk^T = row tid of Fk
-        if (tid < 12) {                              // Fk^T = Pk_i^-1 Pxy: forward + backward substitution per column
-            double rd[12];                           // reciprocal diagonal: twelve divisions instead of twenty-four
-#pragma unroll
-            for (int r = 0; r < 12; ++r) rd[r] = 1.0 / Lblk[pk(12, r, r)];
-#pragma unroll
-            for (int r = 0; r < 12; ++r) {
-                double s = Pxy[r + 12 * tid];
-#pragma unroll
-                for (int p = 0; p < r; ++p) s -= Lblk[pk(12, r, p)] * fk[p];
-                fk[r] = s * rd[r];
-                __builtin_amdgcn_sched_barrier(0);           // (one row of the factor in flight at a time: registers)
-            }
+        if (tid < 12) {                              // Fk^T = Pk_i^-1 Pxy = L^-T M (predict_phase hands out M): backward substitution per column
 #pragma unroll
             for (int r = 11; r >= 0; --r) {
-                double s = fk[r];
+                double s = Pxy[r + 12 * tid];
 #pragma unroll
                 for (int p = r + 1; p < 12; ++p) s -= Lblk[pk(12, p, r)] * fk[p];
-                fk[r] = s * rd[r];
-                __builtin_amdgcn_sched_barrier(0);
+                const double dgl = Lblk[pk(12, r, r)];
+                double rd = __builtin_amdgcn_rcp(dgl);       // reciprocal by two Newton steps (to about an ulp) instead of the division sequence
+                rd = fma(fma(-dgl, rd, 1.0), rd, rd);
+                rd = fma(fma(-dgl, rd, 1.0), rd, rd);
+                fk[r] = s * rd;
+                __builtin_amdgcn_sched_barrier(0);           // (one row of the factor in flight at a time: registers)
             }
         }
         wave_sync();                                 // (every lane has read its part of the factor and of Pxy: CB takes their place)
@@ -390,21 +378,48 @@ __global__ __launch_bounds__(64, SLK_UPRED_WAVES) void usckf_predict_kernel(KArg
             for (int r = 0; r < 12; ++r) Fk[tid + 12 * r] = fk[r];
         }
         wave_sync();
-        for (int e = tid; e < 12 * N; e += 64) {     // rows of state k+i against everything but itself: Fk * old rows
-            const int r = e % 12, c = e / 12;
-            if (c >= 24 && c < 36) continue;
-            double s = 0.0;
-#pragma unroll 4
-            for (int p = 0; p < 12; ++p) s += Fk[r + 12 * p] * RB[p + 12 * c];
-            gP[(24 + r) + (size_t)c * N] = s;
-            if (c >= 36) gP[c + (size_t)(24 + r) * N] = s;          // feature rows against state k+i: the transposes
-        }
-        for (int e = tid; e < 24 * 12; e += 64) {    // columns of state k+i against statek and statek_l: old cols * Fk^T
-            const int r = e % 24, c = e / 24;
-            double s = 0.0;
-#pragma unroll 4
-            for (int p = 0; p < 12; ++p) s += CB[r + 24 * p] * Fk[c + 12 * p];
-            gP[r + (size_t)(24 + c) * N] = s;
+        {
+            // The cross blocks on the matrix cores, transposed so that a lane's results run down a column of P: one
+            // fragment of Fk (lane: Fk(c16, 4 ks + g)) serves both products.
+            const int c16 = tid & 15, g = tid >> 4;
+            double fa[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) { const double v = Fk[(c16 < 12 ? c16 : 0) + 12 * (4 * ks + g)]; fa[ks] = (c16 < 12) ? v : 0.0; }
+            // rows of state k+i against everything but itself: (Fk * old rows)^T = RB^T Fk^T, tile T = columns 16 T .. of P
+#pragma unroll
+            for (int T = 0; T < 3; ++T) {
+                if (16 * T < N) {
+                    const int col = 16 * T + c16;
+                    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) {
+                        const double v = RB[(4 * ks + g) + 12 * (col < N ? col : 0)];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((col < N) ? v : 0.0, fa[ks], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int cc = 16 * T + g + 4 * r;               // column of P; this lane's row is 24 + c16
+                        if (c16 < 12 && cc < N && !(cc >= 24 && cc < 36)) {
+                            gP[(24 + c16) + (size_t)cc * N] = acc[r];
+                            if (cc >= 36) gP[cc + (size_t)(24 + c16) * N] = acc[r];      // feature rows against state k+i: the transposes
+                        }
+                    }
+                }
+            }
+            // columns of state k+i against statek and statek_l: (old cols * Fk^T)^T = Fk CB^T
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                const int row = 16 * T + c16;
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const double v = CB[(row < 24 ? row : 0) + 24 * (4 * ks + g)];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks], (row < 24) ? v : 0.0, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    if (row < 24) gP[row + (size_t)(24 + g + 4 * r) * N] = acc[r];
+            }
         }
         for (int e = tid; e < 144; e += 64) gP[(24 + e % 12) + (size_t)(24 + e / 12) * N] = Pn[e];
         if (tid < 13) gmean[26 + tid] = mu[tid];
