@@ -36,8 +36,8 @@ __device__ __forceinline__ void qrot(const Quat &q, double vx, double vy, double
 
 // MTK cos_sinc_sqrt(x) = (cos(sqrt x), sin(sqrt x)/sqrt x).  Both are entire functions of x:
 //   cos(sqrt x) = sum (-x)^k/(2k)!,   sin(sqrt x)/sqrt x = sum (-x)^k/(2k+1)!
-// For x < 1/4 (rotation below 1 rad, the usual sigma-point spread) the series are summed directly to
-// below 1 ulp (8 terms, Horner) -- no sqrt, no division, no range reduction; MTK itself switches to
+// For x < 1/4 (rotation below 1 rad, the usual sigma-point spread) polynomials of degree 6 / 5 in x stand for the
+// series (near-minimax, below 1 ulp) -- no sqrt, no division, no range reduction; MTK itself switches to
 // this series for tiny x (3 terms below eps^(1/4)).  Larger arguments take the libm route.
 // The libm routes are rare (rotations beyond the series' domain) and register-hungry: kept out of line so that
 // their temporaries and polynomial constants do not count against the callers' register budget.
@@ -62,22 +62,19 @@ template <bool LEAF = false>
 __device__ __forceinline__ void cos_sinc_sqrt(double x, double &c, double &s)
 {
     if (x < 0.25) {
-        const double y = -x;                      // Horner in y = -x
-        double cc = 1.0 / 87178291200.0;          // 1/14!  (x^8/16! < 8e-19 for x < 1/4: far below half an ulp of 1)
-        cc = fma(cc, y, 1.0 / 479001600.0);       // 1/12!
-        cc = fma(cc, y, 1.0 / 3628800.0);         // 1/10!
-        cc = fma(cc, y, 1.0 / 40320.0);           // 1/8!
-        cc = fma(cc, y, 1.0 / 720.0);             // 1/6!
-        cc = fma(cc, y, 1.0 / 24.0);              // 1/4!
-        cc = fma(cc, y, 0.5);                     // 1/2!
+        const double y = -x;                      // Horner in y = -x; near-minimax coefficients (tools/series_coefficients.py):
+        double cc = 0x1.1d8d32755f8fbp-29;     // cos sqrt x, degree 6: relative error 6e-18 on x <= 1/4
+        cc = fma(cc, y, 0x1.27e40964b47d4p-22);
+        cc = fma(cc, y, 0x1.a01a00fb1bc6fp-16);
+        cc = fma(cc, y, 0x1.6c16c16bdd04ep-10);
+        cc = fma(cc, y, 0x1.5555555555421p-5);
+        cc = fma(cc, y, 0x1.fffffffffffffp-2);
         cc = fma(cc, y, 1.0);
-        double ss = 1.0 / 1307674368000.0;        // 1/15!  (x^8/17! < 5e-20)
-        ss = fma(ss, y, 1.0 / 6227020800.0);      // 1/13!
-        ss = fma(ss, y, 1.0 / 39916800.0);        // 1/11!
-        ss = fma(ss, y, 1.0 / 362880.0);          // 1/9!
-        ss = fma(ss, y, 1.0 / 5040.0);            // 1/7!
-        ss = fma(ss, y, 1.0 / 120.0);             // 1/5!
-        ss = fma(ss, y, 1.0 / 6.0);               // 1/3!
+        double ss = 0x1.ac53ce336f805p-26;     // sin sqrt x / sqrt x, degree 5: 4e-17
+        ss = fma(ss, y, 0x1.71dd113fb7905p-19);
+        ss = fma(ss, y, 0x1.a01a01061c190p-13);
+        ss = fma(ss, y, 0x1.11111110ecfb3p-7);
+        ss = fma(ss, y, 0x1.555555555548fp-3);
         ss = fma(ss, y, 1.0);
         c = cc;
         s = ss;
@@ -99,7 +96,7 @@ __device__ __forceinline__ Quat so3_exp(double vx, double vy, double vz)
 
 // MTK::SO3::log: 2 atan(|vec|/w)/|vec| * vec (|vec| clamped to 1e-11).  With u = |vec|/w the factor is
 // 2/w * atan(u)/u and atan(u)/u = sum (-u^2)^k/(2k+1): for u^2 < 1/16 (rotation below ~28 deg) the
-// series is summed directly (13 terms, < 1 ulp) -- one reciprocal instead of sqrt + 2 divisions + atan.
+// series is replaced by a polynomial of degree 8 in u^2 (near-minimax, < 1 ulp) -- one reciprocal instead of sqrt + 2 divisions + atan.
 template <bool LEAF = false>
 __device__ __forceinline__ void so3_log(const Quat &q, double &vx, double &vy, double &vz)
 {
@@ -112,18 +109,14 @@ __device__ __forceinline__ void so3_log(const Quat &q, double &vx, double &vy, d
         rw = fma(fma(-q.w, rw, 1.0), rw, rw);
         rw = fma(fma(-q.w, rw, 1.0), rw, rw);
         const double y = -(n2 * rw * rw);
-        double f = 1.0 / 25.0;                    // (1/16)^13 / 27 < 9e-18: below a tenth of an ulp
-        f = fma(f, y, 1.0 / 23.0);
-        f = fma(f, y, 1.0 / 21.0);
-        f = fma(f, y, 1.0 / 19.0);
-        f = fma(f, y, 1.0 / 17.0);
-        f = fma(f, y, 1.0 / 15.0);
-        f = fma(f, y, 1.0 / 13.0);
-        f = fma(f, y, 1.0 / 11.0);
-        f = fma(f, y, 1.0 / 9.0);
-        f = fma(f, y, 1.0 / 7.0);
-        f = fma(f, y, 1.0 / 5.0);
-        f = fma(f, y, 1.0 / 3.0);
+        double f = 0x1.78be0a9b1dd1fp-5;          // atan(u) / u, degree 8 in y: near-minimax (tools/series_coefficients.py), relative error 9e-18
+        f = fma(f, y, 0x1.0b3340fe2ed9ap-4);
+        f = fma(f, y, 0x1.3ab708d770276p-4);
+        f = fma(f, y, 0x1.7459b99bfc19bp-4);
+        f = fma(f, y, 0x1.c71c5f4b9c2adp-4);
+        f = fma(f, y, 0x1.24924907fa636p-3);
+        f = fma(f, y, 0x1.999999996d307p-3);
+        f = fma(f, y, 0x1.5555555555481p-2);
         f = fma(f, y, 1.0);
         s = 2.0 * f * rw;
     } else {

@@ -101,14 +101,14 @@ __device__ __forceinline__ int fast_vec_storage(int t)
 // lockstep so that every coefficient is fetched once.  A wave whose arguments are all small takes the series directly,
 // otherwise (uniform branch) an angle-halving form that covers the whole domain the fast path can meet; exp beyond 4 rad
 // hands the filter to the general body (flag ints[50], checked after the next barrier, before any global write).
-//   T[0..5]  1/14! 1/12! 1/10! 1/8! 1/6! 1/4!          cos sqrt x   (then 1/2, 1)
-//   T[6..12] 1/15! 1/13! 1/11! 1/9! 1/7! 1/5! 1/3!     sin sqrt x / sqrt x   (then 1)
-//   T[13..24] 1/25 1/23 ... 1/3                        atan u / u   (then 1)
+//   T[0..5]   cos sqrt x            degree 6 in y = -x, x <= 1/4   (then 1)     } near-minimax coefficients of
+//   T[6..10]  sin sqrt x / sqrt x   degree 5                       (then 1)     } tools/series_coefficients.py (relative
+//   T[11..18] atan u / u            degree 8 in y = -u^2, u^2 <= 1/16 (then 1)  } errors 6e-18, 4e-17, 9e-18)
 __device__ const double fast_series_table[26] = {
-    1.0 / 87178291200.0, 1.0 / 479001600.0, 1.0 / 3628800.0, 1.0 / 40320.0, 1.0 / 720.0, 1.0 / 24.0,
-    1.0 / 1307674368000.0, 1.0 / 6227020800.0, 1.0 / 39916800.0, 1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0,
-    1.0 / 25.0, 1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0,
-    1.0 / 3.0, 0.0};
+    0x1.1d8d32755f8fbp-29, 0x1.27e40964b47d4p-22, 0x1.a01a00fb1bc6fp-16, 0x1.6c16c16bdd04ep-10, 0x1.5555555555421p-5, 0x1.fffffffffffffp-2,
+    0x1.ac53ce336f805p-26, 0x1.71dd113fb7905p-19, 0x1.a01a01061c190p-13, 0x1.11111110ecfb3p-7, 0x1.555555555548fp-3,
+    0x1.78be0a9b1dd1fp-5, 0x1.0b3340fe2ed9ap-4, 0x1.3ab708d770276p-4, 0x1.7459b99bfc19bp-4, 0x1.c71c5f4b9c2adp-4, 0x1.24924907fa636p-3, 0x1.999999996d307p-3, 0x1.5555555555481p-2,
+    0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
 // q[i] = exp(v[i]) for NV rotation vectors.  Rotations below 1 rad (every lane of the wave): the series directly; otherwise
 // the series for v / 4 and two quaternion squarings, exp(v) = (exp(v / 4)^2)^2 -- up to 4 rad; ok = false beyond.
@@ -135,17 +135,16 @@ __device__ __forceinline__ bool so3_exp_tab(const double *T, const double (&v)[N
         for (int i = 0; i < NV; ++i) { cc[i] = c0; ss[i] = s0; }
     }
 #pragma unroll
-    for (int k = 1; k < 6; ++k) {
+    for (int k = 1; k < 5; ++k) {
         const double ck = T[k], sk = T[6 + k];
 #pragma unroll
         for (int i = 0; i < NV; ++i) { cc[i] = fma(cc[i], y[i], ck); ss[i] = fma(ss[i], y[i], sk); }
     }
     {
-        const double s6 = T[12];
+        const double c5 = T[5];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            cc[i] = fma(cc[i], y[i], 0.5);
-            ss[i] = fma(ss[i], y[i], s6);
+            cc[i] = fma(cc[i], y[i], c5);
             cc[i] = fma(cc[i], y[i], 1.0);
             ss[i] = fma(ss[i], y[i], 1.0);
         }
@@ -217,13 +216,13 @@ __device__ __forceinline__ bool so3_log_tab(const double *T, const Quat (&q)[NV]
         }
     }
     {
-        const double a0 = T[13];
+        const double a0 = T[11];
 #pragma unroll
         for (int i = 0; i < NV; ++i) f[i] = a0;
     }
 #pragma unroll
-    for (int k = 1; k < 12; ++k) {
-        const double ak = T[13 + k];
+    for (int k = 1; k < 8; ++k) {
+        const double ak = T[11 + k];
 #pragma unroll
         for (int i = 0; i < NV; ++i) f[i] = fma(f[i], y[i], ak);
     }
@@ -812,6 +811,19 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
             bool ok = so3_exp_tab<2>(T, rv, ex);
             ex[0] = qmul(cb, ex[0]);
             ex[1] = qmul(cb, ex[1]);
+#ifdef SLK_STAMPS
+            {   // diagnostic: which waves leave the direct series (bit 0 / 1 of round r: exp / log went the angle-halving way)
+                bool se = true, sl = true;
+                for (int i = 0; i < 2; ++i) {
+                    se = se && (0.25 * (rv[i][0] * rv[i][0] + rv[i][1] * rv[i][1] + rv[i][2] * rv[i][2]) < 0.25);
+                    const double n2 = ex[i].x * ex[i].x + ex[i].y * ex[i].y + ex[i].z * ex[i].z;
+                    sl = sl && (ex[i].w > 0.0) && (n2 * 16.0 < ex[i].w * ex[i].w);
+                }
+                const int code = (__all(se) ? 0 : 1) | (__all(sl) ? 0 : 2);
+                const int slot = wave < 2 ? 26 + wave : 27 + wave;
+                if (lane == 0 && a.dbg && it == 0) a.dbg[(size_t)bidx * 32 + slot] = (r ? a.dbg[(size_t)bidx * 32 + slot] : 0) | (code << (2 * r));
+            }
+#endif
             ok = so3_log_tab<2>(T, ex, dd) && ok;
             if (!__all(ok)) ints[50] = 1;                        // beyond the series' domains
 #pragma unroll

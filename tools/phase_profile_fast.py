@@ -52,6 +52,9 @@ def main():
         print(f"  wave 3: its 20 scans done {m(21, 4):.0f} after stamp 4 (S: {m(6, 4):.0f}); past the park barrier {m(22, 7):.0f} after the gate; "
               f"parked sums + columns {m(23, 22):.0f}")
         print(f"  wave 0: x = S^-1 nu {m(24, 7):.0f} after the gate; b, delta = L b, reference {m(25, 24):.0f}; waits for wave 3 {m(8, 25):.0f}")
+    # which waves left the direct SO(3) series in the first mean-loop pass (bit 0 exp, bit 1 log; wave 1: bits 2 / 3 = its second round)
+    for w, slot in enumerate((26, 27, 29, 30)):
+        print(f"  mean loop, wave {w}: angle-halving exp / log codes {np.bincount(x[:, slot].astype(int), minlength=4)}")
 
 
 if __name__ == "__main__":
