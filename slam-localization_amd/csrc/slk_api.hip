@@ -447,7 +447,10 @@ static int launch_usckf_split(slk_filter *f, const KArgs &a0)
 static int launch_usckf(slk_filter *f, const KArgs &a)
 {
     int NT = (a.lay.N + 15) / 16;
-#ifdef SLK_DEV_N60
+#if defined(SLK_DEV_N60) && defined(SLK_DEV_USCKF)       // (-DSLK_DEV_USCKF: the split path of N <= 48 only)
+    if (NT == 3 && a.emit == 0) return launch_usckf_split<3>(f, a);
+    g_err = "development build: Usckf split path of N <= 48 only"; return SLK_E_UNSUPPORTED;
+#elif defined(SLK_DEV_N60)
     (void)NT; (void)f; (void)a;
     g_err = "development build: Msckf only"; return SLK_E_UNSUPPORTED;
 #else
