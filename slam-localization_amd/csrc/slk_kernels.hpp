@@ -632,9 +632,12 @@ __device__ __forceinline__ int cholp_factor(d4 (&acc)[CholM<NT>::NTL], double *L
 // cycles whether or not it depends on the one before: profiles/r01_mfma_valu_overlap.log), so the count is what is
 // minimised.  No LDS round trip, no branch: a non-positive pivot is recorded (what follows it is never used).
 // 12 x 12: 6.1 k -> 4.6 k cycles including the load of the matrix (profiles/r03_ab_small_state_register_cholesky.log).
+// nst < n: the matrix is padded to n x n with a unit diagonal by the caller, the leading nst x nst part of the factor is stored
+// (packed for nst).
 template <int NMAX, class InitFn>
-__device__ __forceinline__ int chol_rows(double *Lp, int n, int lane, InitFn init)
+__device__ __forceinline__ int chol_rows(double *Lp, int n, int lane, InitFn init, int nst = -1)
 {
+    if (nst < 0) nst = n;
     static_assert(NMAX <= 32, "chol_rows keeps a row per lane in registers");
     double a[NMAX];
 #pragma unroll
@@ -661,10 +664,10 @@ __device__ __forceinline__ int chol_rows(double *Lp, int n, int lane, InitFn ini
             __builtin_amdgcn_sched_barrier(0);       // one column's broadcasts (scalar registers) at a time
         }
     }
-    if (lane < n) {
+    if (lane < nst) {
 #pragma unroll
         for (int j = 0; j < NMAX; ++j)
-            if (j < n && lane >= j) Lp[pk(n, lane, j)] = a[j];
+            if (j < nst && lane >= j) Lp[pk(nst, lane, j)] = a[j];
     }
     wave_sync();
     return bad ? 0 : -1;      // (callers only test the sign)
@@ -826,7 +829,7 @@ __device__ __forceinline__ int cholw_factor(d4 (&acc)[NT], double *Lp, int n, do
 // global workspace that stays in L2 / Infinity Cache.  Left-looking, 16 columns per block step:
 //   1. panel = A[:, J] - L[:, 0:J] L[J, 0:J]^T   one MFMA chain per row tile, fragments read from the
 //      already finished columns in memory, result to an LDS panel ((n - 16J) x 16, ld 17)
-//   2. the 16x16 diagonal tile is factored by wave 0 on the matrix cores (cholm_factor<1>)
+//   2. the 16x16 diagonal tile is factored by wave 0 in registers, lane = row (chol_rows)
 //   3. the rows below are solved against it, one thread per row, and written out.
 template <int NTHREADS, class InitFn>
 __device__ __forceinline__ int chol_blocked_mem(double *Lp, int n, double *panel, double *cb, int *flag,
@@ -881,9 +884,8 @@ __device__ __forceinline__ int chol_blocked_mem(double *Lp, int n, double *panel
         }
         __syncthreads();
         if (wave == 0) {
-            d4 a1[1];
-            cholm_load<1>(a1, ncol, lane, [&](int i, int j) { return panel[i * 17 + j]; });
-            int f0 = cholm_factor<1>(a1, L11, ncol, cb, lane);
+            // (the panel's first sixteen rows carry a unit diagonal beyond ncol already)
+            const int f0 = chol_rows<16>(L11, 16, lane, [&](int i, int j) { return panel[i * 17 + j]; }, ncol);
             if (lane == 0) *flag = f0;
             if (lane < ncol) L11[136 + lane] = 1.0 / L11[pk(ncol, lane, lane)];     // reciprocal pivots for the row solves
         }
