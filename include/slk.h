@@ -134,7 +134,12 @@ int slk_dead_reckon(slk_filter *f, const double *u, int u_stride, double *delta,
  *      in the reference's [r t] order (rotation as a scaled axis first, translation second; Transform.hpp:57-61).
  *      cov2 / cov1 NULL = that side carries no uncertainty (hasUncertainty() false).  additive != 0 is the other branch
  *      of DeadReckon::updatePose's Affine3d overload (src/core/DeadReckon.hpp:306-330): pose = t2 * t1, covariance =
- *      cov2 + cov1 (t2 = prevPose, t1 = deltaPose there).  cov_out may be NULL. ---- */
+ *      cov2 + cov1 (t2 = prevPose, t1 = deltaPose there).  cov_out may be NULL.
+ *      Eigen semantics mirrored (the reference pins no Eigen version and holds no fixture for Transform -- the behaviour
+ *      below is pinned by this library's own tests, parity with the reference is UNPINNED): quaternion from the rotation
+ *      matrix as Eigen::Quaterniond(linear()); q_to_r (Transform.cpp:44-48) as Eigen >= 3.3's AngleAxisd(q), i.e. angle =
+ *      2 atan2(|vec|, |w|) with the axis flipped for w < 0 -- Eigen 3.0 - 3.2 take 2 acos(w) with the axis as it is, which
+ *      gives the other representative of the rotation vector (2 pi apart) for a composite quaternion with w < 0. ---- */
 int slk_transform_compose(slk_filter *f, const double *t2, const double *cov2, const double *t1, const double *cov1,
                           double *t_out, double *cov_out, int additive, int where);
 

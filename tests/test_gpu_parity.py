@@ -282,6 +282,48 @@ def test_llt_failure_is_reported_and_state_kept(slk):
     np.testing.assert_array_equal(f.muState()[1], s["mean"][1])
 
 
+@pytest.mark.parametrize("k", [0, 1, 4, 8, 12, 31])
+@pytest.mark.parametrize("how", ["negated", "late pivot", "nan"])
+def test_llt_failure_in_every_factor_kernel(slk, k, how):
+    """Msckf.hpp:407-413 (Eigen::LLT, info() never read): every factorisation of this library -- the register Cholesky by rows
+    (N = 12 / 18), the one-wave factor kernel by panel rows (N = 36 / 60), the workgroup kernels (N = 84) and the
+    global-workspace one (N = 198) -- reports a covariance that is not positive definite and leaves that filter alone:
+    a negated matrix (first pivot), an indefinite one whose LAST pivot fails, a NaN on the diagonal; update and step."""
+    m = 3 if k == 0 else 8
+    s = sc.synthetic_msckf(3, k, m=(2 if k == 0 else m), seed=77 + k)
+    N = 12 + 6 * k
+    P = s["P"].copy()
+    if how == "negated":
+        P[1] = -P[1]
+    elif how == "late pivot":
+        P[1, N - 1, N - 1] = -1.0
+    else:
+        P[1, N // 2, N // 2] = np.nan
+
+    def update(f):
+        if k == 0:
+            f.update(s["mean"][:, 0:3] + 0.05, slk.MM_POSE_POSITION, np.array([0.0]), 0.01 * np.eye(3), gate=0)
+        else:
+            f.update(s["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+
+    f, good = slk.Msckf(s["mean"], P), slk.Msckf(s["mean"], s["P"])
+    update(f)
+    update(good)
+    st = f.status()
+    assert st[0] == 0 and st[2] == 0 and st[1] & slk.ST_LLT_FAIL
+    got = f.getPk()
+    np.testing.assert_array_equal(got[1], P[1])                       # (NaN == NaN position-wise)
+    np.testing.assert_array_equal(f.muState()[1], s["mean"][1])
+    np.testing.assert_array_equal(got[[0, 2]], good.getPk()[[0, 2]])   # the neighbours are not disturbed
+    if how != "late pivot" or k == 0:              # predict factors the 12 x 12 state block only
+        g = slk.Msckf(s["mean"], P)
+        g.predict(slk.PM_DELTA_POSE, s["u"], s["Q"])
+        bad12 = how == "negated" or (how == "nan" and N // 2 < 12) or (how == "late pivot" and k == 0)
+        assert bool(g.status()[1] & slk.ST_LLT_FAIL) == bad12
+        if bad12:
+            np.testing.assert_array_equal(g.getPk()[1], P[1])
+
+
 def test_api_misuse_is_rejected(slk):
     s = sc.synthetic_msckf(2, 1, m=2, seed=11)
     f = slk.Msckf(s["mean"], s["P"])

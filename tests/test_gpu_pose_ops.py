@@ -43,9 +43,31 @@ def test_transform_compose_against_golden(slk, handle):
     t2 = np.concatenate([rng.normal(size=(24, 3)), sc.quat_exp(rng.normal(0, 2.0, (24, 3)))], axis=1)
     t1 = np.concatenate([rng.normal(size=(24, 3)), sc.quat_exp(rng.normal(0, 2.0, (24, 3)))], axis=1)
     t, c = handle.transform_compose(t2, s["cov2"], t1, s["cov1"])
+    wmin = 1.0
     for b in range(24):
         to, co = o.transform_compose(t2[b], s["cov2"][b], t1[b], s["cov1"][b])
         assert np.abs(t[b] - to).max() <= 1e-11 and np.abs(c[b] - co).max() <= 1e-11 * max(1.0, np.abs(co).max())
+        wmin = min(wmin, to[6])
+    # composite quaternions with w < 0 are among them: q_to_r follows Eigen >= 3.3's AngleAxisd(q) there (angle 2 atan2(|vec|, |w|),
+    # axis flipped), not the 2 acos(w) of Eigen 3.0 - 3.2 -- the reference pins no Eigen version and holds no fixture for
+    # Transform: the chosen behaviour is pinned here, parity with the reference is not
+    assert wmin < -0.1
+
+
+def test_adaptive_attitude_cov_rank_deficient_history(slk):
+    """m1 = 1: Uk is a single outer product (rank one, two zero singular values whose basis JacobiSVD leaves arbitrary,
+    MeasurementModels.hpp:230-235): the GPU op and the oracle take the same basis (cyclic Jacobi from the identity); pinned
+    against each other, parity with the reference unpinned."""
+    s = sc.synthetic_pose_ops()
+    B = s["B"]
+    a = slk.AdaptiveAttitudeCov(B, 1, s["m2"], s["gamma"], s["r2count"])
+    refs = [o.AdaptiveAttitudeCov(1, s["m2"], s["gamma"], s["r2count"]) for _ in range(B)]
+    for k in range(6):
+        R = a.matrix(s["xk"][k], s["Pk"], s["z"][k], s["H"][k], s["R"])
+        for b in range(B):
+            Rb = refs[b].matrix(s["xk"][k][b], s["Pk"][b] if np.ndim(s["Pk"]) == 3 else s["Pk"], s["z"][k][b], s["H"][k][b] if np.ndim(s["H"][k]) == 3 else s["H"][k],
+                                s["R"][b] if np.ndim(s["R"]) == 3 else s["R"])
+            assert np.abs(R[b] - Rb).max() <= 1e-12 * max(1.0, np.abs(Rb).max()), (k, b)
 
 
 @pytest.mark.parametrize("tf", [0, 1])
