@@ -596,8 +596,16 @@ struct CholPSteps {
                     for (int p = 0; p < 4; ++p) colbuf[p * LDC + lane] = l[p];
                 }
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    if (k0 + p < n && lane >= k0 + p && lane < n) Lp[pkcol(n, k0 + p) + lane] = l[p];
+                for (int p = 0; p < 4; ++p) {
+                    // (the column's base pinned in scalar registers: the store is `global_store v_lane8, data, s[base]` -- left to
+                    // itself the compiler keeps ONE base and adds every column's offset with 64-bit vector arithmetic)
+                    // (Lp is global memory here)
+                    typedef __attribute__((address_space(1))) double gdouble;
+                    unsigned long long colb = reinterpret_cast<unsigned long long>(Lp + pkcol(n, k0 + p));
+                    asm volatile("" : "+s"(colb));
+                    gdouble *colp = reinterpret_cast<gdouble *>(colb);
+                    if (k0 + p < n && lane >= k0 + p && lane < n) colp[lane] = l[p];
+                }
                 wave_sync();
                 double frag[NT];
 #pragma unroll
