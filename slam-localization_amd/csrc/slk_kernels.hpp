@@ -426,6 +426,27 @@ __device__ __forceinline__ void cholm_load(d4 (&acc)[CholM<NT>::NTL], int n, int
             }
 }
 
+// The same tiles TRANSPOSED (cholp_factor): lane l, reg r of tile (I, J): row 16I + (l&15), col 16J + (l>>4) + 4r -- sixteen
+// lanes run down a column of the matrix (128 contiguous bytes per request instead of sixteen 32-byte pieces), and the four
+// pivot columns of a step sit in ONE register of every lane, already in the fragment distribution.
+template <int NT, class InitFn>
+__device__ __forceinline__ void cholm_load_t(d4 (&acc)[CholM<NT>::NTL], int n, int lane, InitFn init)
+{
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int J = 0; J < NT; ++J)
+#pragma unroll
+        for (int I = J; I < NT; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = 16 * I + c, col = 16 * J + g + 4 * r;
+                double v;
+                if (row < n && col < n) v = (row >= col) ? init(row, col) : init(col, row);
+                else v = (row == col) ? 1.0 : 0.0;
+                acc[tile_idx(I, J)][r] = -v;          // the accumulators hold -A: the rank-4 updates ADD L L^T
+            }
+}
+
 // acc -= X * Y^T with X, Y n x kk column-major panels in LDS (ld ldx / ldy); column c of X is xcol(c)
 template <int NT, class XFn, class YFn>
 __device__ __forceinline__ void cholm_downdate(d4 (&acc)[CholM<NT>::NTL], int n, int kk, int lane, XFn xel, YFn yel)
@@ -563,14 +584,10 @@ struct CholPSteps {
             if (k0 < n) {
                 const int c = lane & 15, g = lane >> 4;
                 const int row = (NT == 4) ? lane : min(lane, 16 * NT - 1);
-                // 1. publish the four pivot columns, raw (the accumulators hold -A)
-                if (c >= C0 && c < C0 + 4) {
-                    double *dst = colbuf + (c - C0) * LDC + g;
+                // 1. publish the four pivot columns, raw (the accumulators hold -A, tiles transposed: cholm_load_t): register
+                // C0 / 4 of lane (g, c) is element (16 I + c, k0 + g)
 #pragma unroll
-                    for (int I = JK; I < NT; ++I)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dst[16 * I + 4 * r] = acc[tile_idx(I, JK)][r];
-                }
+                for (int I = JK; I < NT; ++I) colbuf[g * LDC + 16 * I + c] = acc[tile_idx(I, JK)][C0 / 4];
                 wave_sync();
                 // 2. this lane's row of the panel, and the four columns
                 double l[4];
@@ -616,14 +633,14 @@ struct CholPSteps {
                 for (int J = JK; J < NT; ++J)
 #pragma unroll
                     for (int I = J; I < NT; ++I)
-                        acc[tile_idx(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[I], frag[J], acc[tile_idx(I, J)], 0, 0, 0);
+                        acc[tile_idx(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[J], frag[I], acc[tile_idx(I, J)], 0, 0, 0);   // (tile^T += L_J L_I^T)
             }
             CholPSteps<NT, (C0 == 12 ? JK + 1 : JK), (C0 + 4) & 15>::run(acc, Lp, n, colbuf, lane, bad);
         }
     }
 };
 
-// factor the matrix held in `acc` (see cholm_load); wave-local, returns -1 or 0 (some pivot was not positive)
+// factor the matrix held in `acc` (see cholm_load_t: TRANSPOSED tiles); wave-local, returns -1 or 0 (some pivot was not positive)
 template <int NT>
 __device__ __forceinline__ int cholp_factor(d4 (&acc)[CholM<NT>::NTL], double *Lp, int n, double *colbuf, int lane)
 {
@@ -3245,10 +3262,11 @@ __global__ __launch_bounds__(64, (NT <= 3 ? 4 : SLK_CHOL1_WAVES)) void msckf_cho
     const int N = (KST >= 0) ? 12 + 6 * KST : a.lay.N;
     const double *gP = a.P + (size_t)bidx * N * N;
     d4 acc[CholM<NT>::NTL];
-    cholm_load<NT>(acc, N, lane, [&](int i, int j) { return gP[i + (size_t)j * N]; });
 #ifdef SLK_CHOL_BY_TILES
+    cholm_load<NT>(acc, N, lane, [&](int i, int j) { return gP[i + (size_t)j * N]; });
     const int fail = cholm_factor<NT>(acc, a.wsL + (size_t)bidx * pk_size(N), N, colbuf, lane);
 #else
+    cholm_load_t<NT>(acc, N, lane, [&](int i, int j) { return gP[i + (size_t)j * N]; });
     const int fail = cholp_factor<NT>(acc, a.wsL + (size_t)bidx * pk_size(N), N, colbuf, lane);
 #endif
     if (lane == 0) a.wsfail[bidx] = fail;
