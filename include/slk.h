@@ -115,7 +115,11 @@ int slk_storage(const slk_filter *f);   /* Nq = stored mean length */
 int slk_set_state(slk_filter *f, const double *mean, const double *P, int where);
 int slk_get_state(slk_filter *f, double *mean, double *P, int where);
 double *slk_mean_device_ptr(slk_filter *f);   /* resident buffers, for zero-copy callers */
-double *slk_cov_device_ptr(slk_filter *f);
+double *slk_cov_device_ptr(slk_filter *f);    /* (the exact-shape Msckf update kernels store the lower triangle and the
+                                                * diagonal tiles of P+ only -- nothing on the device reads more, Msckf.hpp:412, :447 --
+                                                * and this call enqueues the mirror pass that completes the strict upper triangle:
+                                                * call it again after further steps before reading the upper triangle through the
+                                                * pointer; slk_get_state and every other entry point do the same by themselves) */
 
 /* ---- predict(f, Q): Msckf.hpp:89-189, Usckf.hpp:107-244.
  *      u [B][u_stride] model inputs (u_stride 0 = one shared row);

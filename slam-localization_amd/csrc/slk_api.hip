@@ -72,7 +72,13 @@ struct slk_filter {
     std::map<int, Rtab> rtabs;
     hipEvent_t ev0, ev1;
     int rebuild_prec = 0;
+    // The exact-shape Msckf update kernels store P+ as lower triangle + diagonal tiles (KArgs::lower_only); the strict upper
+    // triangle is brought up to date (mirror_upper) before anything but those kernels, predict and the factor kernels --
+    // which read the lower triangle only -- gets to see the matrix.
+    bool upper_stale = false;
 };
+
+static int mirror_upper(slk_filter *f);
 
 static Lay make_lay(int kind, int k, int nfk, int nfkl)
 {
@@ -180,7 +186,11 @@ int slk_batch(const slk_filter *f) { return f ? f->B : SLK_E_INVALID; }
 int slk_dof(const slk_filter *f) { return f ? f->lay.N : SLK_E_INVALID; }
 int slk_storage(const slk_filter *f) { return f ? f->lay.Nq : SLK_E_INVALID; }
 double *slk_mean_device_ptr(slk_filter *f) { return f ? f->d_mean : nullptr; }
-double *slk_cov_device_ptr(slk_filter *f) { return f ? f->d_P : nullptr; }
+double *slk_cov_device_ptr(slk_filter *f)
+{
+    if (!f || mirror_upper(f) != SLK_OK) return nullptr;      // (enqueued on the handle's stream, like every step)
+    return f->d_P;
+}
 
 int slk_set_state(slk_filter *f, const double *mean, const double *P, int where)
 {
@@ -189,7 +199,10 @@ int slk_set_state(slk_filter *f, const double *mean, const double *P, int where)
     hipMemcpyKind kind = where == SLK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     size_t B = (size_t)f->B;
     if (mean) HIPCHECK(hipMemcpyAsync(f->d_mean, mean, B * f->lay.Nq * sizeof(double), kind, f->stream));
-    if (P) HIPCHECK(hipMemcpyAsync(f->d_P, P, B * f->lay.N * f->lay.N * sizeof(double), kind, f->stream));
+    if (P) {
+        HIPCHECK(hipMemcpyAsync(f->d_P, P, B * f->lay.N * f->lay.N * sizeof(double), kind, f->stream));
+        f->upper_stale = false;
+    }
     if (where == SLK_HOST) HIPCHECK(hipStreamSynchronize(f->stream));   // caller may reuse its buffers
     return SLK_OK;
 }
@@ -201,6 +214,7 @@ int slk_get_state(slk_filter *f, double *mean, double *P, int where)
     hipMemcpyKind kind = where == SLK_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     size_t B = (size_t)f->B;
     if (mean) HIPCHECK(hipMemcpyAsync(mean, f->d_mean, B * f->lay.Nq * sizeof(double), kind, f->stream));
+    if (P) { int rc = mirror_upper(f); if (rc) return rc; }
     if (P) HIPCHECK(hipMemcpyAsync(P, f->d_P, B * f->lay.N * f->lay.N * sizeof(double), kind, f->stream));
     if (where == SLK_HOST) HIPCHECK(hipStreamSynchronize(f->stream));
     return SLK_OK;
@@ -254,6 +268,10 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
         if (HasFastStep<NT, NTHREADS, KST, MST>::value) {       // the exact-shape fast path carves LDS its own way
             const size_t fl = (size_t)fast_step_lds_doubles(a.lay.k) * sizeof(double);
             if (fl > lds) lds = fl;
+            if (a.do_update && a.emit == 0 && !a.P_out && a.P == f->d_P) {      // P+ as lower triangle + diagonal tiles (mirror_upper)
+                a.lower_only = 1;
+                f->upper_stale = true;
+            }
         }
         auto kern = msckf_step_kernel<NT, NTHREADS, KST, MST>;
         rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), f->cfg.device, lds);
@@ -343,6 +361,8 @@ static int launch_msckf(slk_filter *f, const KArgs &a0)
 {
     KArgs a = a0;
     int NT = (a.lay.N + 15) / 16;
+    // predict / update / step read the lower triangle of P only (Msckf.hpp:412, :447); everything else gets the whole matrix
+    if (f->upper_stale && (a.emit != 0 || a.P_out)) { int rc = mirror_upper(f); if (rc) return rc; }
     // fused step: NT 3 / 4 launch predict next to the factor kernel themselves, the one-wave kernels (N <= 32) run it inside
     // -- for small batches, where the step time is one filter's latency (B = 1024: 30.5 -> 28.0 us); large batches run the
     // predict chain in its own launch at its own residency (B = 16384: 79.5 against 70.2 M steps/s)
@@ -542,6 +562,16 @@ static int fill_update(slk_filter *f, KArgs &a, int model, const double *params,
     rc = stage_in(f, f->st_z, z, (size_t)f->B * m, where, &a.z);
     if (rc) return rc;
     return stage_in(f, f->st_R, R, r_stride ? (size_t)f->B * r_stride : (size_t)m * m, where, &a.R);
+}
+
+static int mirror_upper(slk_filter *f)
+{
+    if (!f->upper_stale) return SLK_OK;
+    HIPCHECK(hipSetDevice(f->cfg.device));
+    hipLaunchKernelGGL(slk_mirror_upper_kernel, dim3(f->B), dim3(256), 0, f->stream, f->d_P, f->lay.N);
+    HIPCHECK(hipGetLastError());
+    f->upper_stale = false;
+    return SLK_OK;
 }
 
 static int launch(slk_filter *f, const KArgs &a)
@@ -756,6 +786,7 @@ int slk_update_ekf(slk_filter *f, const double *z, const double *zmean, const do
     if (m < N || m > 512 || (m & 1)) return SLK_E_INVALID;       // reduceDimension needs m >= N rows; 2-row blocks
     if (r_stride != 0 && r_stride < m * m) return SLK_E_INVALID;
     HIPCHECK(hipSetDevice(f->cfg.device));
+    { int rcm = mirror_upper(f); if (rcm) return rcm; }
     EkfArgs a;
     memset(&a, 0, sizeof(a));
     a.B = f->B; a.N = N; a.Nq = f->lay.Nq; a.k = f->lay.k; a.m = m; a.gate = gate;
@@ -1070,6 +1101,7 @@ static int msckf_window_op(slk_filter *f, int op, int idx)
     const int k_old = f->lay.k, k_new = op == 1 ? k_old + 1 : k_old - 1;
     if (op == 2 && (idx < 0 || idx >= k_old)) return SLK_E_INVALID;
     HIPCHECK(hipSetDevice(f->cfg.device));
+    { int rcm = mirror_upper(f); if (rcm) return rcm; }          // (the window kernel copies whole blocks of P)
     Lay newL = make_lay(SLK_MSCKF, k_new, 0, 0);
     size_t B = (size_t)f->B;
     // push / pop on the stream into the second buffer pair (no hipMalloc, no synchronisation once it has its size)
@@ -1091,6 +1123,7 @@ int slk_msckf_resize(slk_filter *f, int n_clones)
 {
     if (!f || f->lay.kind != SLK_MSCKF || n_clones < 0) return SLK_E_INVALID;
     HIPCHECK(hipSetDevice(f->cfg.device));
+    f->upper_stale = false;                                        // (the state is zeroed below)
     Lay newL = make_lay(SLK_MSCKF, n_clones, 0, 0);
     size_t B = (size_t)f->B;
     const size_t need_mean = B * newL.Nq, need_P = B * (size_t)newL.N * newL.N;

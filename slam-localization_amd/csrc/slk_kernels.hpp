@@ -39,6 +39,7 @@ struct KArgs {
     // tier B sigma-point emission: 1 = predict sigma points, 2 = update sigma points
     int emit; double *Xout;     // 3 = checkSigmaPoints: re-draw, mean and covariance into mean_out / P_out
     double *mean_out, *P_out;   // null = in place
+    int lower_only;             // the fast path stores the lower triangle (and the diagonal tiles) of P+ only: slk_mirror_upper_kernel later
     int rebuild_prec;     // covariance rebuild arithmetic: 0 = fp64 (parity path), 1 = fp32 MFMA, 2 = bf16 inputs / fp32 accumulate
     double *wsL, *wsDR;   // global workspaces: packed factor (large states N > 80; factor hand-off of msckf_chol_kernel), rotation deviations
     int *wsfail;          // msckf_chol_kernel -> step kernel: first non-positive pivot per filter, or -1
@@ -3322,6 +3323,27 @@ __global__ __launch_bounds__(64, SLK_PRED_WAVES) void msckf_predict_kernel(KArgs
 
 // ------------------------------------------------------------------ MFMA fragment layout self test
 #ifndef SLK_INST_UNIT
+// The strict upper triangle of every covariance from its lower triangle (one workgroup per filter, 16 x 16 tiles through
+// LDS: rows in, rows out).  The exact-shape update kernels store P+ as lower triangle + diagonal tiles (every kernel of this
+// library READS the lower triangle only, Msckf.hpp:412, :447: Eigen::LLT); the host runs this before anything else sees the
+// matrix (slk_get_state, slk_cov_device_ptr, window operations, the EKF update, ...).
+__global__ __launch_bounds__(256) void slk_mirror_upper_kernel(double *P, int N)
+{
+    __shared__ double tile[16][17];
+    double *p = P + (size_t)blockIdx.x * N * N;
+    const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
+    const int nt = (N + 15) / 16;
+    for (int I = 1; I < nt; ++I)
+        for (int J = 0; J < I; ++J) {                 // lower tile (I, J) -> upper tile (J, I)
+            const int row = 16 * I + c, col = 16 * J + r;
+            tile[r][c] = (row < N && col < N) ? p[row + (size_t)col * N] : 0.0;      // tile[col][row]
+            __syncthreads();
+            const int urow = 16 * J + c, ucol = 16 * I + r;                          // P(urow, ucol) = P(ucol, urow) = tile[urow - 16J][ucol - 16I]
+            if (urow < N && ucol < N) p[urow + (size_t)ucol * N] = tile[c][r];
+            __syncthreads();
+        }
+}
+
 __global__ void selftest_mfma_kernel(const double *Amat /*16x4 row-major*/, const double *Bmat /*4x16 row-major*/,
                                      double *C /*16x16 row-major*/)
 {

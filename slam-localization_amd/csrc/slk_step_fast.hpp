@@ -435,7 +435,7 @@ __device__ __forceinline__ void fast_rebuild_col(const double *Lt, const double 
 // ... + p d0^T + d0 p^T (one k-step: A = [p, d0], B = [d0, p]) and out: the mirror triangle straight from the accumulators,
 // the lower triangle of the off-diagonal tiles through a private 16 x 17 transpose buffer.
 template <int K, int J>
-__device__ __forceinline__ void fast_store_col(const double *pd, double *bufs, double *oP, int lane, d4 (&acc)[FastShape<K>::NT])
+__device__ __forceinline__ void fast_store_col(const double *pd, double *bufs, double *oP, int lane, d4 (&acc)[FastShape<K>::NT], bool lower_only)
 {
     using F = FastShape<K>;
     constexpr int NT = F::NT, N = F::N;
@@ -456,6 +456,7 @@ __device__ __forceinline__ void fast_store_col(const double *pd, double *bufs, d
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                // acc[r] of lane (c, g) = P+(16 I + g + 4 r, 16 J + c) -> P(col, row)
             const bool full = 16 * I + 4 * r + 3 < N && 16 * J + 15 < N;
+            if (I > J && lower_only) continue;       // (the mirror triangle is brought up to date when somebody wants it)
             if (16 * I + 4 * r < N && (full || (16 * I + 4 * r + g < N && 16 * J + c < N)))
                 o[16 * J + (16 * I + 4 * r) * N] = acc[I - J][r];
         }
@@ -955,10 +956,10 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
     else if constexpr (NT > 3) fast_rebuild_col<K, 3>(Lt, Et, str, lane, acc);
     __syncthreads();                                             // factor and E^ are dead; p is complete
     SLK_FSTAMP(14);
-    if (wave == 0) fast_store_col<K, 0>(pd, Lt, oP, lane, acc);
-    else if (wave == 1) fast_store_col<K, 1>(pd, Lt, oP, lane, acc);
-    else if (wave == 2) fast_store_col<K, 2>(pd, Lt, oP, lane, acc);
-    else if constexpr (NT > 3) fast_store_col<K, 3>(pd, Lt, oP, lane, acc);
+    if (wave == 0) fast_store_col<K, 0>(pd, Lt, oP, lane, acc, a.lower_only != 0);
+    else if (wave == 1) fast_store_col<K, 1>(pd, Lt, oP, lane, acc, a.lower_only != 0);
+    else if (wave == 2) fast_store_col<K, 2>(pd, Lt, oP, lane, acc, a.lower_only != 0);
+    else if constexpr (NT > 3) fast_store_col<K, 3>(pd, Lt, oP, lane, acc, a.lower_only != 0);
     SLK_STAMP_NR(15);
     return true;
 }

@@ -593,6 +593,52 @@ def test_dead_reckon_delta_and_fused_predict(slk):
     assert np.abs(out.reshape(-1)[:104].reshape(8, 13) - g["delta"][:8]).max() <= 1e-14
 
 
+@pytest.mark.parametrize("k", [4, 8])
+def test_strict_upper_triangle_is_completed_on_demand(slk, k):
+    """The exact-shape update kernels (k = 4 .. 8, m = 8) store P+ as lower triangle + diagonal tiles; nothing on the device
+    reads more (Msckf.hpp:412, :447 -- Eigen::LLT).  Everything that hands the matrix out completes it first: slk_get_state,
+    the zero-copy pointer, the window operations, the EKF update."""
+    import torch
+    B = 6
+    s = sc.synthetic_msckf(B, k, m=8, seed=1234 + k)
+    N = 12 + 6 * k
+
+    def stepped(n):
+        f = slk.Msckf(s["mean"], s["P"])
+        for _ in range(n):
+            f.step(slk.PM_DELTA_POSE, s["u"], s["Q"], s["z"], slk.MM_FEATURE_PROJ, s["feat"], s["R"])
+        return f
+
+    f = stepped(3)
+    assert (f.status() == 0).all()
+    P = f.getPk()
+    assert np.abs(P - np.transpose(P, (0, 2, 1))).max() == 0.0            # slk_get_state: exactly symmetric
+    # against the oracle (whole matrix)
+    for b in range(2):
+        r = o.Msckf(k, s["mean"][b], s["P"][b])
+        for _ in range(3):
+            u = s["u"][b]
+            assert r.predict(o.pm_delta_pose(u[0:3], u[3:7], u[7:10], u[10:13]), s["Q"]) == 0
+            r.update(s["z"][b], o.mm_feature_proj(s["feat"][b]), s["R"])
+        assert np.abs(P[b] - r.P).max() / np.abs(r.P).max() <= 1e-9
+    # zero-copy: the pointer call completes the strict upper triangle on the handle's stream
+    g = stepped(3)
+    _, cov = g.device_pointers()
+    g.sync()
+    import ctypes as C
+    host = np.empty((B, N, N))
+    assert torch.cuda.is_available()
+    rt = C.CDLL("libamdhip64.so")
+    assert rt.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(cov), C.c_size_t(host.nbytes), 2) == 0      # hipMemcpyDeviceToHost
+    np.testing.assert_array_equal(np.transpose(host, (0, 2, 1)), P)
+    # a window operation right after the steps (whole blocks of P are copied), then the read-out
+    h = stepped(3)
+    h.clone_pose()
+    Ph = h.getPk()
+    assert np.abs(Ph - np.transpose(Ph, (0, 2, 1))).max() == 0.0
+    np.testing.assert_array_equal(Ph[:, :N, :N], P)
+
+
 def test_msckf_device_side_window_sliding(slk):
     # SURVEY 8f-2: clone push / pop on the device (the reference's callers do muState().sensorsk push/pop + setPk,
     # Msckf.hpp:381-395); checked against the same index manipulation in numpy and a following step in the oracle
