@@ -434,18 +434,31 @@ static int launch_usckf_split(slk_filter *f, const KArgs &a0)
         if (!a.do_update) return SLK_OK;
         a.do_predict = 0;
     }
-    int rc = stage_reserve(f, f->ws_L, (size_t)a.B * pk_size(a.lay.N));
-    if (rc) return rc;
-    rc = stage_reserve(f, f->ws_DR, ((size_t)a.B * sizeof(int) + sizeof(double) - 1) / sizeof(double));
-    if (rc) return rc;
-    a.wsL = f->ws_L.p;
-    a.wsfail = reinterpret_cast<int *>(f->ws_DR.p);
-    if (NT == 3 && a.lay.N == 48) {             // the unit-test shape: the exact-size factor kernel (same N as 6 Msckf clones)
-        hipLaunchKernelGGL((msckf_chol_kernel<3, 6>), dim3(a.B), dim3(64), 0, f->stream, a);
+    // the exact shape with the plain update factors inside the update kernel (slk_usckf_fast.hpp): two launches per step,
+    // no factor round trip through memory (-DSLK_USCKF_FACTOR_KERNEL: the three-launch form, for A/B runs)
+    bool fused_factor = false;
+#ifndef SLK_USCKF_FACTOR_KERNEL
+    if constexpr (NT == 3)
+        fused_factor = a.lay.nfk == 3 && a.lay.nfkl == 9 && a.m == 3 && a.emit == 0 && a.mm == SLK_MM_VO_RELATIVE && a.gate <= 9;
+#endif
+    int rc = SLK_OK;
+    if (fused_factor) {
+        a.wsL = nullptr;
+        a.wsfail = nullptr;
     } else {
-        hipLaunchKernelGGL((msckf_chol_kernel<NT, -1>), dim3(a.B), dim3(64), 0, f->stream, a);
+        rc = stage_reserve(f, f->ws_L, (size_t)a.B * pk_size(a.lay.N));
+        if (rc) return rc;
+        rc = stage_reserve(f, f->ws_DR, ((size_t)a.B * sizeof(int) + sizeof(double) - 1) / sizeof(double));
+        if (rc) return rc;
+        a.wsL = f->ws_L.p;
+        a.wsfail = reinterpret_cast<int *>(f->ws_DR.p);
+        if (NT == 3 && a.lay.N == 48) {             // the unit-test shape: the exact-size factor kernel (same N as 6 Msckf clones)
+            hipLaunchKernelGGL((msckf_chol_kernel<3, 6>), dim3(a.B), dim3(64), 0, f->stream, a);
+        } else {
+            hipLaunchKernelGGL((msckf_chol_kernel<NT, -1>), dim3(a.B), dim3(64), 0, f->stream, a);
+        }
+        HIPCHECK(hipGetLastError());
     }
-    HIPCHECK(hipGetLastError());
     UCarve cv = carve_usckf(a.lay.N, a.lay.Nq, a.m, NT, true);
     const size_t lds = (size_t)cv.total * sizeof(double);
 #ifndef SLK_USCKF_UPD_THREADS

@@ -575,7 +575,7 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
 // rows -- per column: pivot by v_readlane, v_rsq_f64 + two Newton steps, one scale, one multiply-add per remaining
 // panel column -- written to LDS again and fetched as the matrix-core fragments of the rank-4 update; the packed factor
 // is stored straight from the row layout.  A non-positive pivot is recorded; what follows it is never used.
-template <int NT, int JK, int C0>
+template <int NT, int JK, int C0, bool GOUT = true>
 struct CholPSteps {
     __device__ __forceinline__ static void run(d4 (&acc)[CholM<NT>::NTL], double *Lp, int n, double *colbuf, int lane, bool &bad)
     {
@@ -617,12 +617,16 @@ struct CholPSteps {
                 for (int p = 0; p < 4; ++p) {
                     // (the column's base pinned in scalar registers: the store is `global_store v_lane8, data, s[base]` -- left to
                     // itself the compiler keeps ONE base and adds every column's offset with 64-bit vector arithmetic)
-                    // (Lp is global memory here)
-                    typedef __attribute__((address_space(1))) double gdouble;
-                    unsigned long long colb = reinterpret_cast<unsigned long long>(Lp + pkcol(n, k0 + p));
-                    asm volatile("" : "+s"(colb));
-                    gdouble *colp = reinterpret_cast<gdouble *>(colb);
-                    if (k0 + p < n && lane >= k0 + p && lane < n) colp[lane] = l[p];
+                    // (GOUT: Lp is global memory; otherwise LDS -- immediate offsets do it there)
+                    if constexpr (GOUT) {
+                        typedef __attribute__((address_space(1))) double gdouble;
+                        unsigned long long colb = reinterpret_cast<unsigned long long>(Lp + pkcol(n, k0 + p));
+                        asm volatile("" : "+s"(colb));
+                        gdouble *colp = reinterpret_cast<gdouble *>(colb);
+                        if (k0 + p < n && lane >= k0 + p && lane < n) colp[lane] = l[p];
+                    } else {
+                        if (k0 + p < n && lane >= k0 + p && lane < n) Lp[pkcol(n, k0 + p) + lane] = l[p];
+                    }
                 }
                 wave_sync();
                 double frag[NT];
@@ -636,17 +640,17 @@ struct CholPSteps {
                     for (int I = J; I < NT; ++I)
                         acc[tile_idx(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[J], frag[I], acc[tile_idx(I, J)], 0, 0, 0);   // (tile^T += L_J L_I^T)
             }
-            CholPSteps<NT, (C0 == 12 ? JK + 1 : JK), (C0 + 4) & 15>::run(acc, Lp, n, colbuf, lane, bad);
+            CholPSteps<NT, (C0 == 12 ? JK + 1 : JK), (C0 + 4) & 15, GOUT>::run(acc, Lp, n, colbuf, lane, bad);
         }
     }
 };
 
 // factor the matrix held in `acc` (see cholm_load_t: TRANSPOSED tiles); wave-local, returns -1 or 0 (some pivot was not positive)
-template <int NT>
+template <int NT, bool GOUT = true>
 __device__ __forceinline__ int cholp_factor(d4 (&acc)[CholM<NT>::NTL], double *Lp, int n, double *colbuf, int lane)
 {
     bool bad = false;
-    CholPSteps<NT, 0, 0>::run(acc, Lp, n, colbuf, lane, bad);
+    CholPSteps<NT, 0, 0, GOUT>::run(acc, Lp, n, colbuf, lane, bad);
     wave_sync();
     return bad ? 0 : -1;
 }

@@ -136,7 +136,20 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
     if (a.do_update || a.emit == 2) {
         // ---- Usckf::update, Usckf.hpp:246-308
         int fail;
-        if constexpr (SPLIT) {
+        if (SPLIT && NT <= 4 && !a.wsfail) {
+            // no factor in the workspace (the exact-shape launch factors inside the update kernel, slk_usckf_fast.hpp, and
+            // this body is its fallback): one wave, panel by rows, straight into LDS
+            if constexpr (NT <= 4) {
+                if (wave == 0) {
+                    d4 acc[CholM<NT>::NTL];
+                    cholm_load_t<NT>(acc, N, lane, [&](int i, int j) { return gP[i + (size_t)j * N]; });
+                    const int f0 = cholp_factor<NT, false>(acc, Lm, N, colbuf, lane);
+                    if (lane == 0) ish[45] = f0;
+                }
+            }
+            __syncthreads();
+            fail = ish[45];
+        } else if constexpr (SPLIT) {
             const double *gL = a.wsL + (size_t)bidx * pk_size(N);
             for (int e0 = 0; e0 < pk_size(N); e0 += 12 * NTHREADS) {      // twelve loads in flight per thread
                 double v[12];

@@ -1,7 +1,7 @@
 // slk_usckf_fast.hpp -- exact-shape fast path of Usckf::update (reference src/filters/Usckf.hpp:246-308, sigma points :532-561,
 // moments :630-737) for the unit-test layout (test/UsckfUnitTest.cpp: statek, statek_l, statek_i, 3 + 9 features: N = 48;
-// the relative-transform measurement model :62-86, m = 3 rows), 128 threads = two waves per filter, the packed factor of
-// msckf_chol_kernel in LDS, the covariance in global memory.
+// the relative-transform measurement model :62-86, m = 3 rows), 128 threads = two waves per filter, the packed factor in
+// LDS (factored by wave 0 at the top of the kernel -- cholp_factor -- or handed over by msckf_chol_kernel), the covariance in global memory.
 //   * wave 0 evaluates h at the "+" sigma point of column j = lane, wave 1 at the "-" one (lanes >= 48 evaluate X_0: Z_0 by
 //     v_readlane), both SO(3) exponentials of a point in lockstep with the series coefficients in an LDS table;
 //   * mean_z, innovation and S = 1/2 sum (Z - mean_z)(Z - mean_z)^T + R from wave reductions of the deviations about Z_0;
@@ -33,7 +33,7 @@ __device__ __forceinline__ bool usckf_update_fast(const KArgs &a, double *smem)
 {
     using F = UFast;
     constexpr int N = F::N, Nq = F::Nq, S = F::S;
-    if (a.mm != SLK_MM_VO_RELATIVE || a.emit != 0 || a.m != 3 || !a.do_update || a.do_predict || !a.wsfail || a.gate > 9) return false;
+    if (a.mm != SLK_MM_VO_RELATIVE || a.emit != 0 || a.m != 3 || !a.do_update || a.do_predict || a.gate > 9) return false;
     const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double *Lp = smem + F::oL, *mu = smem + F::oMu, *T = smem + F::oT, *Yp = smem + F::oYp, *Ym = smem + F::oYm, *red = smem + F::oRed;
@@ -43,20 +43,32 @@ __device__ __forceinline__ bool usckf_update_fast(const KArgs &a, double *smem)
     double *gP = a.P + (size_t)bidx * N * N;
     // ---- load: factor, mean, series table; the conditions that hand the filter to the general body meet in one barrier
     {
-        const double *gL = a.wsL + (size_t)bidx * pk_size(N);
+        // the factor: from msckf_chol_kernel's workspace, or (a.wsfail == nullptr) factored HERE by wave 0 -- panel by rows,
+        // straight into LDS, no round trip through memory (Usckf.hpp:532-538); the colbuf of the factorisation is the Yp array
+        const bool here = a.wsfail == nullptr;
+        const double *gL = here ? gP : a.wsL + (size_t)bidx * pk_size(N);
         double v[10];
+        int bad = 0;
+        if (!here) {
 #pragma unroll
-        for (int q = 0; q < 10; ++q) { const int e = tid + 128 * q; v[q] = gL[e < pk_size(N) ? e : 0]; }
+            for (int q = 0; q < 10; ++q) { const int e = tid + 128 * q; v[q] = gL[e < pk_size(N) ? e : 0]; }
+            bad = a.wsfail[bidx] >= 0;
+        } else if (wave == 0) {
+            d4 acc[CholM<3>::NTL];
+            cholm_load_t<3>(acc, N, lane, [&](int i, int j) { return gP[i + (size_t)j * N]; });
+            bad = cholp_factor<3, false>(acc, Lp, N, Yp, lane) >= 0;
+        }
         const double m0 = (tid < Nq) ? gmean[tid] : 0.0;
         const double tv = fast_series_table[tid < 26 ? tid : 25];
-        int bad = a.wsfail[bidx] >= 0;
         if (tid < 3) {                                          // rotation rows 3..5 of the three single states (Usckf.hpp:553-556)
             const int t0 = 12 * tid + 3;
             const double sd = gP[t0 * (N + 1)] + gP[(t0 + 1) * (N + 1)] + gP[(t0 + 2) * (N + 1)];
             bad |= !(sd < 9.869604401089358);
         }
+        if (!here) {
 #pragma unroll
-        for (int q = 0; q < 10; ++q) { const int e = tid + 128 * q; if (e < pk_size(N)) Lp[e] = v[q]; }
+            for (int q = 0; q < 10; ++q) { const int e = tid + 128 * q; if (e < pk_size(N)) Lp[e] = v[q]; }
+        }
         if (tid < Nq) mu[tid] = m0;
         if (tid < 26) T[tid] = tv;
         if (tid < 2) flags[tid] = 0;
