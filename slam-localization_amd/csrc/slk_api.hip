@@ -428,6 +428,17 @@ template <int NT>
 static int launch_usckf_split(slk_filter *f, const KArgs &a0)
 {
     KArgs a = a0;
+    // The unit-test shape keeps the lower triangle (and the diagonal 16 x 16 tiles) of the covariance up to date only:
+    // predict, the factorisation and the exact-shape update read nothing else (Usckf.hpp:537: Eigen::LLT); the strict upper
+    // triangle is completed before anything else sees the matrix (mirror_upper).  -DSLK_USCKF_FULL_P: both triangles, always.
+#ifndef SLK_USCKF_FULL_P
+    if (NT == 3 && a.lay.N == 48 && a.lay.nfk == 3 && a.lay.nfkl == 9 && a.emit == 0 && !a.P_out && a.P == f->d_P
+        && (!a.do_update || (a.m == 3 && a.mm == SLK_MM_VO_RELATIVE && a.gate <= 9))) {
+        a.lower_only = 1;
+        f->upper_stale = true;
+    } else
+#endif
+    { int rcm = mirror_upper(f); if (rcm) return rcm; }
     if (a.do_predict) {
         hipLaunchKernelGGL(usckf_predict_kernel, dim3(a.B), dim3(64), 0, f->stream, a);
         HIPCHECK(hipGetLastError());
@@ -480,6 +491,7 @@ static int launch_usckf_split(slk_filter *f, const KArgs &a0)
 static int launch_usckf(slk_filter *f, const KArgs &a)
 {
     int NT = (a.lay.N + 15) / 16;
+    if (f->upper_stale && (a.emit != 0 || a.lay.N > 48)) { int rcm = mirror_upper(f); if (rcm) return rcm; }   // (the fused kernels stage the whole matrix)
 #if defined(SLK_DEV_N60) && defined(SLK_DEV_USCKF)       // (-DSLK_DEV_USCKF: the split path of N <= 48 only)
     if (NT == 3 && a.emit == 0) return launch_usckf_split<3>(f, a);
     g_err = "development build: Usckf split path of N <= 48 only"; return SLK_E_UNSUPPORTED;
@@ -1042,6 +1054,7 @@ int slk_usckf_cloning(slk_filter *f, int mode)
     if (!f || f->lay.kind != SLK_USCKF) return SLK_E_INVALID;
     if (mode != SLK_STATEK_I && mode != SLK_STATEK_L) return SLK_OK;   // default: break (Usckf.hpp:428-429)
     HIPCHECK(hipSetDevice(f->cfg.device));
+    { int rcm = mirror_upper(f); if (rcm) return rcm; }          // (whole blocks of P are copied)
     int total = f->B * 256;
     hipLaunchKernelGGL(usckf_cloning_kernel, dim3((total + 255) / 256), dim3(256), 0, f->stream,
                        f->d_mean, f->d_P, f->B, f->lay.N, f->lay.Nq, mode);
@@ -1084,6 +1097,7 @@ int slk_usckf_set_measurement(slk_filter *f, int mode, const double *z, int n, c
     if (!f || f->lay.kind != SLK_USCKF || !z || !R || n < 1) return SLK_E_INVALID;
     if (mode != SLK_STATEK && mode != SLK_STATEK_L) return SLK_OK;
     HIPCHECK(hipSetDevice(f->cfg.device));
+    { int rcm = mirror_upper(f); if (rcm) return rcm; }          // (whole blocks of P are copied)
     Lay oldL = f->lay;
     int nfk = mode == SLK_STATEK ? n : oldL.nfk, nfkl = mode == SLK_STATEK_L ? n : oldL.nfkl;
     Lay newL = make_lay(SLK_USCKF, 0, nfk, nfkl);

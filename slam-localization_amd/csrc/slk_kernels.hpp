@@ -3329,7 +3329,8 @@ __global__ __launch_bounds__(64, SLK_PRED_WAVES) void msckf_predict_kernel(KArgs
 #ifndef SLK_INST_UNIT
 // The strict upper triangle of every covariance from its lower triangle (one workgroup per filter, 16 x 16 tiles through
 // LDS: rows in, rows out).  The exact-shape update kernels store P+ as lower triangle + diagonal tiles (every kernel of this
-// library READS the lower triangle only, Msckf.hpp:412, :447: Eigen::LLT); the host runs this before anything else sees the
+// library READS the lower triangle only, Msckf.hpp:412, :447: Eigen::LLT; the Usckf predict keeps nothing but the lower
+// triangle proper up to date); the host runs this before anything else sees the
 // matrix (slk_get_state, slk_cov_device_ptr, window operations, the EKF update, ...).
 __global__ __launch_bounds__(256) void slk_mirror_upper_kernel(double *P, int N)
 {
@@ -3337,13 +3338,13 @@ __global__ __launch_bounds__(256) void slk_mirror_upper_kernel(double *P, int N)
     double *p = P + (size_t)blockIdx.x * N * N;
     const int c = threadIdx.x & 15, r = threadIdx.x >> 4;
     const int nt = (N + 15) / 16;
-    for (int I = 1; I < nt; ++I)
-        for (int J = 0; J < I; ++J) {                 // lower tile (I, J) -> upper tile (J, I)
+    for (int I = 0; I < nt; ++I)
+        for (int J = 0; J <= I; ++J) {                // lower tile (I, J) -> upper tile (J, I); a diagonal tile onto itself
             const int row = 16 * I + c, col = 16 * J + r;
             tile[r][c] = (row < N && col < N) ? p[row + (size_t)col * N] : 0.0;      // tile[col][row]
             __syncthreads();
             const int urow = 16 * J + c, ucol = 16 * I + r;                          // P(urow, ucol) = P(ucol, urow) = tile[urow - 16J][ucol - 16I]
-            if (urow < N && ucol < N) p[urow + (size_t)ucol * N] = tile[c][r];
+            if (urow < N && ucol < N && urow < ucol) p[urow + (size_t)ucol * N] = tile[c][r];
             __syncthreads();
         }
 }

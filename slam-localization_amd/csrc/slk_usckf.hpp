@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64, SLK_UPRED_WAVES) void usckf_predict_kernel(KArg
     __shared__ __attribute__((aligned(16))) double sm[16 + 3 * 160 + 736];
     const int bidx = blockIdx.x, tid = threadIdx.x;
     const int N = a.lay.N, Nq = a.lay.Nq;
-    double *mu = sm, *Pn = sm + 16, *Lblk = Pn + 160, *Pxy = Lblk + 160, *scr = Pxy + 160, *CB = Lblk;
+    double *mu = sm, *Pn = sm + 16, *Lblk = Pn + 160, *Pxy = Lblk + 160, *scr = Pxy + 160;
     double *RB = scr, *Fk = scr + 580;              // 12 x N (N <= 48: 576) + 144 <= 736
     double *gmean = a.mean + (size_t)bidx * Nq;
     double *gP = a.P + (size_t)bidx * N * N;
@@ -356,17 +356,28 @@ __global__ __launch_bounds__(64, SLK_UPRED_WAVES) void usckf_predict_kernel(KArg
                                        Lblk, mu, Pn, scr, Pxy);
     if (st < 0) return;                              // sigma points emitted
     if (!(st & SLK_ST_LLT_FAIL)) {
-        // the old columns of state k+i (rows < 24) leave for the registers now: their round trip runs under the Fk solve
-        double cv[5];
+        // the old rows 24..35 (12 x N, ld 12) to LDS before the first write (the predict scratch is dead), read from the LOWER
+        // triangle only (columns beyond the block: the transposed entries, fetched along their columns); the old columns of
+        // state k+i against statek / statek_l are the transposes of the first 24 of these rows -- no fetch of their own
+        {
+            double ra[7], rb[3];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) { const int e = tid + 64 * q; cv[q] = (e < 24 * 12) ? gP[(e % 24) + (size_t)(24 + e / 24) * N] : 0.0; }
-        // the old rows 24..35 (12 x N, ld 12) to LDS before the first write (the predict scratch is dead), six loads in flight
-        for (int e0 = 0; e0 < 12 * N; e0 += 6 * 64) {
-            double rv[6];
+            for (int q = 0; q < 7; ++q) {                                      // columns 0 .. 35: down the columns (inside the block: the lower triangle)
+                const int e = tid + 64 * q, p = e % 12, c = e / 12, row = 24 + p;
+                ra[q] = (e < 12 * 36) ? gP[c > row ? c + (size_t)row * N : row + (size_t)c * N] : 0.0;
+            }
 #pragma unroll
-            for (int q = 0; q < 6; ++q) { const int e = e0 + tid + 64 * q; rv[q] = (e < 12 * N) ? gP[(24 + e % 12) + (size_t)(e / 12) * N] : 0.0; }
+            for (int q = 0; q < 3; ++q) {                                      // columns 36 .. N - 1: P(c, 24 + p), c fastest
+                const int e = tid + 64 * q, cq = e % 12, p = e / 12;
+                rb[q] = (e < 144 && 36 + cq < N) ? gP[(36 + cq) + (size_t)(24 + p) * N] : 0.0;
+            }
 #pragma unroll
-            for (int q = 0; q < 6; ++q) { const int e = e0 + tid + 64 * q; if (e < 12 * N) RB[e] = rv[q]; }
+            for (int q = 0; q < 7; ++q) { const int e = tid + 64 * q; if (e < 12 * 36) RB[e] = ra[q]; }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int e = tid + 64 * q, cq = e % 12, p = e / 12;
+                if (e < 144 && 36 + cq < N) RB[p + 12 * (36 + cq)] = rb[q];
+            }
         }
         double fk[12];                               // lanes < 12: column tid of Fk^T = row tid of Fk
         if (tid < 12) {                              // Fk^T = Pk_i^-1 Pxy = L^-T M (predict_phase hands out M): backward substitution per column
@@ -383,9 +394,7 @@ __global__ __launch_bounds__(64, SLK_UPRED_WAVES) void usckf_predict_kernel(KArg
                 __builtin_amdgcn_sched_barrier(0);           // (one row of the factor in flight at a time: registers)
             }
         }
-        wave_sync();                                 // (every lane has read its part of the factor and of Pxy: CB takes their place)
-#pragma unroll
-        for (int q = 0; q < 5; ++q) { const int e = tid + 64 * q; if (e < 24 * 12) CB[e] = cv[q]; }
+        wave_sync();
         if (tid < 12) {
 #pragma unroll
             for (int r = 0; r < 12; ++r) Fk[tid + 12 * r] = fk[r];
@@ -413,20 +422,21 @@ __global__ __launch_bounds__(64, SLK_UPRED_WAVES) void usckf_predict_kernel(KArg
                     for (int r = 0; r < 4; ++r) {
                         const int cc = 16 * T + g + 4 * r;               // column of P; this lane's row is 24 + c16
                         if (c16 < 12 && cc < N && !(cc >= 24 && cc < 36)) {
-                            gP[(24 + c16) + (size_t)cc * N] = acc[r];
+                            if (cc < 24 || !a.lower_only) gP[(24 + c16) + (size_t)cc * N] = acc[r];
                             if (cc >= 36) gP[cc + (size_t)(24 + c16) * N] = acc[r];      // feature rows against state k+i: the transposes
                         }
                     }
                 }
             }
-            // columns of state k+i against statek and statek_l: (old cols * Fk^T)^T = Fk CB^T
+            // columns of state k+i against statek and statek_l: (old cols * Fk^T)^T = Fk CB^T -- the transposes of the rows
+            // above (nothing to do when only the lower triangle is kept up to date)
 #pragma unroll
-            for (int T = 0; T < 2; ++T) {
+            for (int T = 0; T < 2 && !a.lower_only; ++T) {
                 const int row = 16 * T + c16;
                 d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int ks = 0; ks < 3; ++ks) {
-                    const double v = CB[(row < 24 ? row : 0) + 24 * (4 * ks + g)];
+                    const double v = RB[(4 * ks + g) + 12 * (row < 24 ? row : 0)];      // old column entry (row, 24 + k) = old row entry (24 + k, row)
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks], (row < 24) ? v : 0.0, acc, 0, 0, 0);
                 }
 #pragma unroll

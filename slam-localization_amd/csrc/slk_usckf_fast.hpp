@@ -183,7 +183,28 @@ __device__ __forceinline__ bool usckf_update_fast(const KArgs &a, double *smem)
     }
     __syncthreads();
     // ---- Pk -= K S K^T (:296; K S = covXZ): read-modify-write of the covariance in global memory, its loads first
-    {
+    if (a.lower_only) {
+        // the six lower 16 x 16 tiles only (the diagonal ones whole): nothing on the device reads the strict upper triangle
+        // (Usckf.hpp:537: Eigen::LLT), the host completes it when somebody wants the matrix (slk_mirror_upper_kernel)
+        const int r = tid & 15, c0 = tid >> 4;
+        double pv[12];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int I = t < 1 ? 0 : (t < 3 ? 1 : 2), J = t - I * (I + 1) / 2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) pv[2 * t + h] = gP[(16 * I + r) + (size_t)(16 * J + c0 + 8 * h) * N];
+        }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int I = t < 1 ? 0 : (t < 3 ? 1 : 2), J = t - I * (I + 1) / 2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = 16 * I + r, jc = 16 * J + c0 + 8 * h;
+                const double s = Px[4 * i] * Kg[4 * jc] + Px[4 * i + 1] * Kg[4 * jc + 1] + Px[4 * i + 2] * Kg[4 * jc + 2];
+                gP[i + (size_t)jc * N] = pv[2 * t + h] - s;
+            }
+        }
+    } else {
         double pv[18];
 #pragma unroll
         for (int q = 0; q < 18; ++q) pv[q] = gP[tid + 128 * q];

@@ -462,6 +462,39 @@ def test_usckf_spd_predict_update_against_golden_and_oracle(slk):
     np.testing.assert_array_equal(h.muState(), M)
 
 
+def test_usckf_lower_triangle_steady_state_and_completion_on_demand(slk):
+    """The unit-test shape keeps only the lower triangle of the covariance up to date between steps (predict, the in-kernel
+    factorisation and the exact-shape update read nothing else, Usckf.hpp:537); whatever hands the matrix out or copies
+    blocks of it completes the strict upper triangle first."""
+    s = sc.synthetic_usckf(4)
+    f = slk.Usckf(mean=s["mean"], P=s["P"], nfk=3, nfkl=9)
+    for _ in range(3):
+        f.step(slk.PM_CONST_VELOCITY, s["u"], s["Q"], s["z"], slk.MM_VO_RELATIVE, None, s["R"])
+    assert (f.status() == 0).all()
+    P = f.PkAugmentedState()
+    assert np.abs(P - np.transpose(P, (0, 2, 1))).max() == 0.0
+    om, oP = s["mean"].copy(), np.ascontiguousarray(np.transpose(s["P"], (0, 2, 1))).reshape(4, -1)
+    assert o.usckf_step_batch(3, 9, 3, om, oP, s["u"], s["z"], s["Q"], s["R"]) == 0
+    for b in range(4):
+        assert rel(P[b], oP[b].reshape(48, 48).T) <= TOL
+    # cloning right after the steps (copies blocks of both triangles) == cloning of a handle that was given the whole matrix
+    g = slk.Usckf(mean=s["mean"], P=s["P"], nfk=3, nfkl=9)
+    for _ in range(3):
+        g.step(slk.PM_CONST_VELOCITY, s["u"], s["Q"], s["z"], slk.MM_VO_RELATIVE, None, s["R"])
+    g.cloning(slk.STATEK_I)
+    h = slk.Usckf(mean=f.muState(), P=P, nfk=3, nfkl=9)
+    h.cloning(slk.STATEK_I)
+    np.testing.assert_array_equal(g.PkAugmentedState(), h.PkAugmentedState())
+    # a different measurement model after lower-triangle steps (the general kernel stages the whole matrix)
+    g2 = slk.Usckf(mean=s["mean"], P=s["P"], nfk=3, nfkl=9)
+    h2 = slk.Usckf(mean=s["mean"], P=s["P"], nfk=3, nfkl=9)
+    g2.step(slk.PM_CONST_VELOCITY, s["u"], s["Q"], s["z"], slk.MM_VO_RELATIVE, None, s["R"])
+    h2.step(slk.PM_CONST_VELOCITY, s["u"], s["Q"], s["z"], slk.MM_VO_RELATIVE, None, s["R"])
+    h2 = slk.Usckf(mean=h2.muState(), P=h2.PkAugmentedState(), nfk=3, nfkl=9)        # (the whole matrix, through the host)
+    X = g2.update_sigma_points()
+    np.testing.assert_array_equal(X, h2.update_sigma_points())
+
+
 @pytest.mark.parametrize("nfk,nfkl", [(3, 0), (3, 18), (3, 23)])
 def test_usckf_other_feature_counts_against_oracle(slk, nfk, nfkl):
     # N = 39 and 57 take the three-launch path (predict / factor / update), N = 62 the fused kernel
