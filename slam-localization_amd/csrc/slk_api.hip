@@ -272,6 +272,9 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
                 a.lower_only = 1;
                 f->upper_stale = true;
             }
+#ifndef SLK_MSCKF_FACTOR_KERNEL      // the first factorisation inside the update kernel's fast path: two launches per step, no factor round trip
+            if (a.do_update && a.emit == 0 && a.mm == SLK_MM_FEATURE_PROJ && a.m == 8 && a.gate != 2 && a.rebuild_prec == 0 && a.mp) a.wsfail = nullptr;
+#endif
         }
         auto kern = msckf_step_kernel<NT, NTHREADS, KST, MST>;
         rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), f->cfg.device, lds);
@@ -282,8 +285,10 @@ static int launch_msckf_inst(slk_filter *f, const KArgs &a0)
                 HIPCHECK(hipGetLastError());
                 s.do_predict = 0;                   // the step kernel takes the predicted state from memory
             }
-            hipLaunchKernelGGL((msckf_chol_kernel<NT, KST>), dim3(s.B), dim3(64), 0, st, s);
-            HIPCHECK(hipGetLastError());
+            if (s.wsfail) {
+                hipLaunchKernelGGL((msckf_chol_kernel<NT, KST>), dim3(s.B), dim3(64), 0, st, s);
+                HIPCHECK(hipGetLastError());
+            }
             hipLaunchKernelGGL(kern, dim3(s.B), dim3(NTHREADS), lds, st, s);
             HIPCHECK(hipGetLastError());
             return SLK_OK;

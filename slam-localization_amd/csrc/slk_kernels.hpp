@@ -575,14 +575,17 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
 // rows -- per column: pivot by v_readlane, v_rsq_f64 + two Newton steps, one scale, one multiply-add per remaining
 // panel column -- written to LDS again and fetched as the matrix-core fragments of the rank-4 update; the packed factor
 // is stored straight from the row layout.  A non-positive pivot is recorded; what follows it is never used.
-template <int NT, int JK, int C0, bool GOUT = true>
+// OUT: where the factor goes -- 0: packed, LDS; 1: packed, global memory; 2: the 16 x 16 tiles of the exact-shape update kernel
+// (slk_step_fast.hpp: tile (I, J) at (I (I + 1) / 2 + J) * 256, element (t, j) at (j & 15) * 16 + (t & 15), exact zeros above the
+// diagonal and in the padding), LDS
+template <int NT, int JK, int C0, int OUT = 1>
 struct CholPSteps {
     __device__ __forceinline__ static void run(d4 (&acc)[CholM<NT>::NTL], double *Lp, int n, double *colbuf, int lane, bool &bad)
     {
         if constexpr (JK < NT) {
             constexpr int LDC = CholM<NT>::LDC;
             constexpr int k0 = 16 * JK + C0;
-            if (k0 < n) {
+            if (OUT == 2 || k0 < n) {
                 const int c = lane & 15, g = lane >> 4;
                 const int row = (NT == 4) ? lane : min(lane, 16 * NT - 1);
                 // 1. publish the four pivot columns, raw (the accumulators hold -A, tiles transposed: cholm_load_t): register
@@ -597,7 +600,12 @@ struct CholPSteps {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const double d = readlane_f64(l[p], k0 + p);
-                    bad |= !(d > 0.0);
+                    {   // (tested here and now: left alone the compiler keeps all sixty pivots for one test at the end -- in scalar
+                        // registers it does not have, i.e. spilled lane by lane; the flag goes through a vector register)
+                        int nb = !(d > 0.0);
+                        asm volatile("" : "+v"(nb));
+                        bad |= (nb != 0);
+                    }
                     double sq, rs;
                     rsqrt_pivot(d, sq, rs);
                     (void)sq;
@@ -617,8 +625,12 @@ struct CholPSteps {
                 for (int p = 0; p < 4; ++p) {
                     // (the column's base pinned in scalar registers: the store is `global_store v_lane8, data, s[base]` -- left to
                     // itself the compiler keeps ONE base and adds every column's offset with 64-bit vector arithmetic)
-                    // (GOUT: Lp is global memory; otherwise LDS -- immediate offsets do it there)
-                    if constexpr (GOUT) {
+                    if constexpr (OUT == 2) {
+                        if (lane >= 16 * JK && (NT == 4 || lane < 16 * NT)) {
+                            const int It = lane >> 4;
+                            Lp[(It * (It + 1) / 2 + JK) * 256 + (C0 + p) * 16 + (lane & 15)] = (k0 + p < n && lane >= k0 + p) ? l[p] : 0.0;
+                        }
+                    } else if constexpr (OUT == 1) {
                         typedef __attribute__((address_space(1))) double gdouble;
                         unsigned long long colb = reinterpret_cast<unsigned long long>(Lp + pkcol(n, k0 + p));
                         asm volatile("" : "+s"(colb));
@@ -640,17 +652,17 @@ struct CholPSteps {
                     for (int I = J; I < NT; ++I)
                         acc[tile_idx(I, J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[J], frag[I], acc[tile_idx(I, J)], 0, 0, 0);   // (tile^T += L_J L_I^T)
             }
-            CholPSteps<NT, (C0 == 12 ? JK + 1 : JK), (C0 + 4) & 15, GOUT>::run(acc, Lp, n, colbuf, lane, bad);
+            CholPSteps<NT, (C0 == 12 ? JK + 1 : JK), (C0 + 4) & 15, OUT>::run(acc, Lp, n, colbuf, lane, bad);
         }
     }
 };
 
 // factor the matrix held in `acc` (see cholm_load_t: TRANSPOSED tiles); wave-local, returns -1 or 0 (some pivot was not positive)
-template <int NT, bool GOUT = true>
+template <int NT, int OUT = 1>
 __device__ __forceinline__ int cholp_factor(d4 (&acc)[CholM<NT>::NTL], double *Lp, int n, double *colbuf, int lane)
 {
     bool bad = false;
-    CholPSteps<NT, 0, 0, GOUT>::run(acc, Lp, n, colbuf, lane, bad);
+    CholPSteps<NT, 0, 0, OUT>::run(acc, Lp, n, colbuf, lane, bad);
     wave_sync();
     return bad ? 0 : -1;
 }
@@ -2067,7 +2079,25 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
     if (a.do_update || a.emit >= 2) {
         // ---- sigma points of the full state: Msckf.hpp:228-229 -> :400-431
         int fail;
-        if constexpr (WCHOL) {
+#ifndef SLK_MSCKF_FACTOR_KERNEL
+        constexpr bool FACTOR_INSIDE = true;
+#else
+        constexpr bool FACTOR_INSIDE = false;
+#endif
+        if (FACTOR_INSIDE && WCHOL && !a.wsfail) {
+            // no factor in the workspace (the exact-shape launch factors inside the fast path, and this body is its fallback):
+            // one wave, panel by rows, straight into LDS
+            if constexpr (WCHOL && FACTOR_INSIDE) {
+                if (wave == 0) {
+                    d4 acc[CholM<NT>::NTL];
+                    cholm_load_t<NT>(acc, N, lane, Pin);
+                    const int f0 = cholp_factor<NT, 0>(acc, Lp, N, colbuf, lane);
+                    if (lane == 0) ish[45] = f0;
+                }
+            }
+            __syncthreads();
+            fail = ish[45];
+        } else if constexpr (WCHOL) {
             // the factor comes from msckf_chol_kernel (its own launch, one wave per filter at twelve filters per CU),
             // packed, through a workspace
             const double *gL = a.wsL + (size_t)bidx * pk_size(N);

@@ -481,7 +481,7 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
     using F = FastShape<K>;
     constexpr int N = F::N, Nq = F::Nq, S = F::S, NSO3 = F::NSO3, NT = F::NT, NKS = F::NKS, NROT = F::NROT;
     constexpr int NP = F::NP;
-    if (a.mm != SLK_MM_FEATURE_PROJ || a.gate == 2 || a.emit != 0 || a.rebuild_prec != 0 || !a.mp || a.m != 8 || !a.wsfail) return false;
+    if (a.mm != SLK_MM_FEATURE_PROJ || a.gate == 2 || a.emit != 0 || a.rebuild_prec != 0 || !a.mp || a.m != 8) return false;
     const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g4 = lane >> 4;
@@ -500,22 +500,32 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
     // hand the filter to the general body -- failed first factorisation, pose index out of range (SLK_ST_BAD_INDEX there),
     // a rotation column that may exceed pi (Msckf.hpp:407-413: covXZ = L A would not hold) -- meet in one barrier
     int jmax = 0, bad;
+    // the factor: from msckf_chol_kernel's workspace, or (a.wsfail == nullptr) factored HERE by wave 0 -- cholp_factor, panel
+    // by rows, straight into the tiles -- while the other waves fetch the small arrays
+#ifndef SLK_MSCKF_FACTOR_KERNEL     // (-DSLK_MSCKF_FACTOR_KERNEL: the three-launch form, the factor through the workspace only -- same step time,
+    const bool here = a.wsfail == nullptr;       //  1.28 x instead of 0.74 x the algorithmic bytes: profiles/r03_ab_msckf_factor_inside.log)
+#else
+    constexpr bool here = false;
+    if (!a.wsfail) return false;
+#endif
     {
-        const double *gL = a.wsL + (size_t)bidx * pk_size(N);
+        const double *gL = here ? gP : a.wsL + (size_t)bidx * pk_size(N);
         const int t = lane, It = t >> 4;
         const int lbase = (It * (It + 1) / 2) * 256 + wave * 16 + (t & 15);
         double v[16];
+        if (!here) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int j = 4 * u + wave;
-            const bool in = j < N && t >= j && t < N;
-            v[u] = gL[in ? pkcol(N, j) + t : 0];
+            for (int u = 0; u < 16; ++u) {
+                const int j = 4 * u + wave;
+                const bool in = j < N && t >= j && t < N;
+                v[u] = gL[in ? pkcol(N, j) + t : 0];
+            }
         }
         const double mu0 = (tid < Nq) ? gmean[tid] : 0.0;
         const int t0 = (tid && tid < NSO3) ? 9 + 6 * tid : 3;
         const double pdg = gP[t0 * (N + 1)] + gP[(t0 + 1) * (N + 1)] + gP[(t0 + 2) * (N + 1)];
         const double tabv = fast_series_table[tid < 26 ? tid : 25];
-        bad = a.wsfail[bidx] >= 0;
+        bad = here ? 0 : (a.wsfail[bidx] >= 0);
         bool ok = true;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
@@ -530,11 +540,19 @@ __device__ __forceinline__ bool msckf_step_fast(const KArgs &a, double *smem)
         if (tid < 64) { str[tid] = 0.0; pd[tid] = 0.0; ints[tid] = 0; }
         if (tid < 32) { d0[tid] = 0.0; md32[tid] = 0.0; }
         if (tid < 26) T[tid] = tabv;
+        if (!here) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int j = 4 * u + wave;
-            const bool in = j < N && t >= j && t < N;
-            if ((u >> 2) < NT && It >= (u >> 2) && It < NT) Lt[lbase + (u >> 2) * 256 + (u & 3) * 64] = in ? v[u] : 0.0;
+            for (int u = 0; u < 16; ++u) {
+                const int j = 4 * u + wave;
+                const bool in = j < N && t >= j && t < N;
+                if ((u >> 2) < NT && It >= (u >> 2) && It < NT) Lt[lbase + (u >> 2) * 256 + (u & 3) * 64] = in ? v[u] : 0.0;
+            }
+        }
+        // (after the stores above: the sixteen loaded values must not live across this region)
+        if (here && wave == 0) {
+            d4 fa[CholM<NT>::NTL];
+            cholm_load_t<NT>(fa, N, lane, [&](int i, int j) { return gP[i + (size_t)j * N]; });
+            bad |= cholp_factor<NT, 2>(fa, Lt, N, U, lane) >= 0;      // (the union region is free until phase 1: its colbuf)
         }
     }
     if (__syncthreads_or(bad)) SLK_FBAIL(2);

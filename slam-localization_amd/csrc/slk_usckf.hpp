@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NTHREADS) void usckf_kernel(KArgs a)
                 if (wave == 0) {
                     d4 acc[CholM<NT>::NTL];
                     cholm_load_t<NT>(acc, N, lane, [&](int i, int j) { return gP[i + (size_t)j * N]; });
-                    const int f0 = cholp_factor<NT, false>(acc, Lm, N, colbuf, lane);
+                    const int f0 = cholp_factor<NT, 0>(acc, Lm, N, colbuf, lane);
                     if (lane == 0) ish[45] = f0;
                 }
             }

@@ -56,7 +56,7 @@ __device__ __forceinline__ bool usckf_update_fast(const KArgs &a, double *smem)
         } else if (wave == 0) {
             d4 acc[CholM<3>::NTL];
             cholm_load_t<3>(acc, N, lane, [&](int i, int j) { return gP[i + (size_t)j * N]; });
-            bad = cholp_factor<3, false>(acc, Lp, N, Yp, lane) >= 0;
+            bad = cholp_factor<3, 0>(acc, Lp, N, Yp, lane) >= 0;
         }
         const double m0 = (tid < Nq) ? gmean[tid] : 0.0;
         const double tv = fast_series_table[tid < 26 ? tid : 25];
