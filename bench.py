@@ -357,7 +357,9 @@ def report(args, w, world, per_rank):
     # applyDelta rebuild, 3.7 flop/B): priced against the HBM roof with the algorithmic bytes of 8(d).
     mfma_bound = N >= 48 and not usckf
     if usckf:
-        kernel = "usckf_predict_kernel + msckf_chol_kernel + usckf_kernel (one filter step = three launches)"
+        kernel = "usckf_predict_kernel + usckf_kernel with the factorisation inside (one filter step = two launches)"
+    elif 32 < N <= 64 and m == 8:
+        kernel = "msckf_predict_kernel + msckf_step_kernel with the first factorisation inside (one filter step = two launches)"
     elif 32 < N <= 64:
         kernel = "msckf_predict_kernel + msckf_chol_kernel + msckf_step_kernel (one filter step = three launches)"
     else:
