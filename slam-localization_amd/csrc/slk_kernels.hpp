@@ -2180,6 +2180,42 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                 }
                 ldm_prefix(ldm_a, ldm_pf);
             };
+            // A measurement that is LINEAR in the tangent space (the position fix of a pose: Z_i = mu_pos +- L(tp + r, j)) has its
+            // sigma-point moments in closed form -- mean_z = h(mu), S = (L L^T)(rows, rows) + R = P(rows, rows) + R, covXZ =
+            // L L(rows, :)^T = P(:, rows) (Msckf.hpp:231-239 in exact arithmetic; rounding apart, 1e-16) -- as long as no rotation
+            // column can wrap (X_i [-] mu = +-L(:, j)): the exact-shape kernel of BASELINE config 2 (N = 12, three rows) takes it
+            bool closed_form = false;
+            if constexpr (NT == 1 && KST == 0 && MST == 3) {
+                if (a.mm == SLK_MM_POSE_POSITION && a.emit == 0) {
+                    bool nowrap = true;
+                    for (int b = 0; b < nso3; ++b) {
+                        const int t0 = so3_toff(L, b);
+                        nowrap = nowrap && (Pin(t0, t0) + Pin(t0 + 1, t0 + 1) + Pin(t0 + 2, t0 + 2) < 9.869604401089358);
+                    }
+                    if (nowrap) {                                       // (uniform)
+                        const double *mp = a.mp + (size_t)bidx * a.mp_stride;
+                        const double *R = a.R + (size_t)bidx * a.r_stride;
+                        int tp, sp, pb;
+                        pose_of(L, (int)mp[0], tp, sp, pb);
+                        if (tid < 3) {
+                            const double zb = mu[sp + tid];
+                            zbar[tid] = zb;
+                            innov[tid] = a.z[(size_t)bidx * 3 + tid] - zb;
+                        }
+                        if (tid < 9) {
+                            const int r = tid % 3, c = tid / 3, i = tp + (r > c ? r : c), j = tp + (r > c ? c : r);
+                            Sm[r + 3 * c] = Pin(i, j) + R[r + 3 * c];
+                        }
+                        if (tid < 3 * N) {
+                            const int t = tid % N, c = tid / N, i = t > tp + c ? t : tp + c, j = t > tp + c ? tp + c : t;
+                            Pxz[t + N * c] = Pin(i, j);
+                        }
+                        __syncthreads();
+                        closed_form = true;
+                    }
+                }
+            }
+            if (!closed_form)
             measurement_moments<NTHREADS>(a, L, bidx, tid, mu, Lp, Z, DZ, Pxz, Sm, zbar, innov, &ish[42],
                                            [&](int t) { return Pin(t, t); }, colbuf, cv.pool - cv.colbuf,
                                            WCHOL && NW == 4 && m <= 8 && a.emit == 0,
