@@ -2193,6 +2193,8 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                         nowrap = nowrap && (Pin(t0, t0) + Pin(t0 + 1, t0 + 1) + Pin(t0 + 2, t0 + 2) < 9.869604401089358);
                     }
                     if (nowrap) {                                       // (uniform)
+                        SLK_STAMP_NR(4);
+                        SLK_STAMP_NR(5);
                         const double *mp = a.mp + (size_t)bidx * a.mp_stride;
                         const double *R = a.R + (size_t)bidx * a.r_stride;
                         int tp, sp, pb;
