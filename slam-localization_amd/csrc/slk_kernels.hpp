@@ -2187,12 +2187,14 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
             bool closed_form = false;
             if constexpr (NT == 1 && KST == 0 && MST == 3) {
                 if (a.mm == SLK_MM_POSE_POSITION && a.emit == 0) {
-                    bool nowrap = true;
-                    for (int b = 0; b < nso3; ++b) {
-                        const int t0 = so3_toff(L, b);
-                        nowrap = nowrap && (Pin(t0, t0) + Pin(t0 + 1, t0 + 1) + Pin(t0 + 2, t0 + 2) < 9.869604401089358);
-                    }
-                    if (nowrap) {                                       // (uniform)
+                    // (after a predict in this launch the whole matrix is the 12 x 12 block in LDS: no global access)
+                    auto closed = [&](auto Pacc) __attribute__((always_inline)) -> bool {
+                        bool nowrap = true;
+                        for (int b = 0; b < nso3; ++b) {
+                            const int t0 = so3_toff(L, b);
+                            nowrap = nowrap && (Pacc(t0, t0) + Pacc(t0 + 1, t0 + 1) + Pacc(t0 + 2, t0 + 2) < 9.869604401089358);
+                        }
+                        if (!nowrap) return false;                      // (uniform)
                         SLK_STAMP_NR(4);
                         SLK_STAMP_NR(5);
                         const double *mp = a.mp + (size_t)bidx * a.mp_stride;
@@ -2206,15 +2208,17 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
                         }
                         if (tid < 9) {
                             const int r = tid % 3, c = tid / 3, i = tp + (r > c ? r : c), j = tp + (r > c ? c : r);
-                            Sm[r + 3 * c] = Pin(i, j) + R[r + 3 * c];
+                            Sm[r + 3 * c] = Pacc(i, j) + R[r + 3 * c];
                         }
                         if (tid < 3 * N) {
                             const int t = tid % N, c = tid / N, i = t > tp + c ? t : tp + c, j = t > tp + c ? tp + c : t;
-                            Pxz[t + N * c] = Pin(i, j);
+                            Pxz[t + N * c] = Pacc(i, j);
                         }
                         __syncthreads();
-                        closed_form = true;
-                    }
+                        return true;
+                    };
+                    if (pred12) closed_form = closed([&](int i, int j) { return Pn12[i + 12 * j]; });
+                    else closed_form = closed([&](int i, int j) { return gP[i + (size_t)j * N]; });
                 }
             }
             if (!closed_form)
