@@ -10,7 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-STAMPS = [(0, "entry"), (3, "load: mean, tiled factor"), (4, "Z = h(X), zbar, innovation"), (6, "S (wave 0)"), (7, "gate"),
+STAMPS = [(0, "entry"), (3, "load + first factorisation (wave 0), mean, small arrays"), (4, "Z = h(X), zbar, innovation"), (6, "S (wave 0)"), (7, "gate"),
           (8, "x, b, delta (wave 0) | scan + columns (wave 3)"), (11, "factor update L M"), (12, "mean loop"),
           (13, "correction, odd / even split, mean out"), (14, "rebuild MFMA"), (15, "rank-2 + store")]
 
