@@ -3321,12 +3321,13 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS >= 256 && NT >= 3 && NT <= 4 ? 
 
 // ------------------------------------------------------------------ the Msckf factor kernel
 // generateSigmaPoints' Cholesky of the full covariance (Msckf.hpp:407-413, Eigen::LLT) for 32 < N <= 64, in its own
-// launch: ONE wave per filter (cholm_factor: all ten tiles in registers, no workgroup barrier, 2 KB of LDS, 168
-// registers -> three waves per SIMD), the packed factor handed to the step kernel through a workspace.  Every wave runs
-// the whole 15-step chain on its own and the chip holds twelve filters per CU; measured 45.7 us per 4096 filters against
-// 68 us for the four-waves-per-filter version (two barriers per step, six workgroups per CU): the launch moves 150 MB
-// (P in, L out) at 3.3 TB/s, i.e. it is close to the HBM roof rather than latency-bound.  Fusing the predict chain into
-// the same wave, and a 128-register build at four waves per SIMD, measured the same step time.
+// launch: ONE wave per filter (cholp_factor: all ten tiles in registers as transposed matrix-core accumulators, the four
+// pivot columns of a step factored once for all rows, no workgroup barrier, 2 KB of LDS, 116 registers -> four waves per
+// SIMD, sixteen filters per CU), the packed factor handed to the step kernel through a workspace.  36.4 us per 4096
+// filters (round 2, cholm_factor at 168 registers: 45.7 us; four waves per filter, two barriers per step: 68 us).
+// The exact shapes of the fast path (k = 4 .. 8 clones, eight rows) and the Usckf unit-test shape run the same
+// factorisation INSIDE their update kernels instead (no factor round trip through memory): this kernel serves the other
+// shapes of N <= 64 and the -DSLK_MSCKF_FACTOR_KERNEL / -DSLK_USCKF_FACTOR_KERNEL builds; -DSLK_CHOL_BY_TILES: round 2's form.
 #ifndef SLK_CHOL1_WAVES
 #define SLK_CHOL1_WAVES 3
 #endif
